@@ -1,0 +1,331 @@
+/*
+ * ORACLE -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * Plain-C CPU restatement of the reference's ARCTE hot path, used ONLY as the
+ * checker by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+ * Nothing under reveal-graph-embedding_amd/ may import, link or call it.
+ *
+ * Parity status: PINNED.  The reference ships no tests or golden vectors
+ * (SURVEY.md section 4), so the pins are outputs of the reference itself, run
+ * in the build container by tests/golden/make_golden.py and committed as
+ * tests/golden/ (.npz files); tests/test_oracle_golden.py checks every function below
+ * against them bit for bit.
+ *
+ * Reference files restated (paths relative to /root/reference/reveal_graph_embedding):
+ *   eps_randomwalk/push.py:41-64          -> oracle_push
+ *   eps_randomwalk/similarity.py:149-222  -> oracle_similarity
+ *   embedding/arcte/arcte.py:26-50        -> oracle_epsilon_effective
+ *   embedding/arcte/arcte.py:279-388      -> oracle_worker (per-seed body 337-376)
+ *
+ * Arithmetic is IEEE binary64 with the reference's operation order; build with
+ * -ffp-contract=off so `c*w` then `+` never fuses into an FMA (push.py:62-64).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ------------------------------------------------------------------------ */
+/* numpy's pairwise summation (numpy/_core/src/umath/loops_utils.h.src,       */
+/* @TYPE@_pairwise_sum): what ndarray.mean() runs for a contiguous float64    */
+/* vector, arcte.py:32 (checked against np.sum bit for bit in the tests).      */
+/* ------------------------------------------------------------------------ */
+static double np_pairwise(const double *a, int64_t n)
+{
+    if (n < 8) {
+        double res = 0.0;
+        for (int64_t i = 0; i < n; i++) res += a[i];
+        return res;
+    } else if (n <= 128) {
+        double r[8];
+        int64_t i;
+        for (int j = 0; j < 8; j++) r[j] = a[j];
+        for (i = 8; i < n - (n % 8); i += 8)
+            for (int j = 0; j < 8; j++) r[j] += a[i + j];
+        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; i++) res += a[i];
+        return res;
+    } else {
+        int64_t n2 = n / 2;
+        n2 -= n2 % 8;
+        return np_pairwise(a, n2) + np_pairwise(a + n2, n - n2);
+    }
+}
+
+double oracle_np_sum(const double *a, int64_t n)
+{
+    return np_pairwise(a, n);
+}
+
+/* arcte.py:26-50.  rho and mean_degree are accepted and unused there. */
+double oracle_epsilon_effective(double epsilon, double seed_degree,
+                                const double *neighbor_degrees, int64_t m)
+{
+    double neighborhood_degree = oracle_np_sum(neighbor_degrees, m) / (double)m;          /* :32 */
+    double e = (epsilon * log(1 + seed_degree)) / log(1 + neighborhood_degree);         /* :35 */
+    double emax = -INFINITY, emin = INFINITY;
+    for (int64_t i = 0; i < m; i++) {                                                    /* :39-40 */
+        double x = 1 / (seed_degree * neighbor_degrees[i]);
+        if (x > emax) emax = x;
+        if (x < emin) emin = x;
+    }
+    if (e > emax) e = emax;                                                              /* :45-48 */
+    else if (e < emin) e = (emin + e) / 2;
+    return e;
+}
+
+/* push.py:41-64: one cumulative-difference push of `push_node` over its CSR row. */
+void oracle_push(double *s, double *r, const double *w_i, const int32_t *a_i, int64_t deg,
+                 int64_t push_node, double rho)
+{
+    double commute = (1 - rho) * r[push_node];     /* :56 */
+    r[push_node] = 0.0;                            /* :59 */
+    for (int64_t k = 0; k < deg; k++) {            /* :62-64, distinct targets */
+        double p = commute * w_i[k];
+        s[a_i[k]] += p;
+        r[a_i[k]] += p;
+    }
+}
+
+/* growable FIFO standing in for collections.deque (similarity.py:180) */
+typedef struct { int32_t *buf; int64_t cap, head, tail; } fifo_t;
+
+static int fifo_push(fifo_t *q, int32_t v)
+{
+    if (q->tail == q->cap) {
+        if (q->head > q->cap / 2) {
+            memmove(q->buf, q->buf + q->head, (size_t)(q->tail - q->head) * sizeof(int32_t));
+            q->tail -= q->head;
+            q->head = 0;
+        } else {
+            int64_t ncap = q->cap ? q->cap * 2 : 1024;
+            int32_t *nb = (int32_t *)realloc(q->buf, (size_t)ncap * sizeof(int32_t));
+            if (!nb) return -1;
+            q->buf = nb;
+            q->cap = ncap;
+        }
+    }
+    q->buf[q->tail++] = v;
+    return 0;
+}
+
+typedef struct {
+    int64_t pushes, edges, enqueues, support;
+} oracle_stats_t;
+
+/* first-touch bookkeeping: `touched` receives every index whose s went 0 -> nonzero */
+static inline void deposit(double *s, double *r, int32_t v, double p, int32_t *touched, int64_t *ntouched)
+{
+    double s_old = s[v];
+    double s_new = s_old + p;
+    s[v] = s_new;
+    r[v] += p;
+    if (touched && s_old == 0.0 && s_new != 0.0) touched[(*ntouched)++] = v;
+}
+
+static int64_t similarity_core(const int64_t *indptr, const int32_t *indices, const double *data,
+                               const double *in_degree, int64_t seed, double rho, double epsilon,
+                               double *s, double *r, fifo_t *q, int32_t *touched, int64_t *ntouched,
+                               oracle_stats_t *st)
+{
+    int64_t nop = 0;
+    if (touched && s[seed] == 0.0) touched[(*ntouched)++] = (int32_t)seed;
+    s[seed] = 1.0;                                           /* similarity.py:176 */
+    r[seed] = 1.0;                                           /* :177 */
+    q->head = q->tail = 0;
+    int64_t u = seed;
+    int first = 1;
+    for (;;) {
+        if (!first) {
+            if (q->head == q->tail) break;                   /* :199 */
+            u = q->buf[q->head++];                           /* :200 */
+        }
+        /* :186 unconditional first push; :204 threshold at pop time afterwards */
+        if (first || r[u] / in_degree[u] >= epsilon) {
+            double commute = (1 - rho) * r[u];               /* push.py:56 */
+            r[u] = 0.0;                                      /* push.py:59 */
+            int64_t b = indptr[u], e = indptr[u + 1];
+            for (int64_t k = b; k < e; k++)                  /* push.py:62-64 */
+                deposit(s, r, indices[k], commute * data[k], touched, ntouched);
+            nop++;
+            for (int64_t k = b; k < e; k++) {                /* similarity.py:194-196 / :214-216, CSR order */
+                int32_t v = indices[k];
+                if (r[v] / in_degree[v] >= epsilon) {
+                    if (fifo_push(q, v)) return -1;
+                    if (st) st->enqueues++;
+                }
+            }
+            if (st) { st->pushes++; st->edges += e - b; }
+        }
+        first = 0;
+    }
+    return nop;
+}
+
+/* similarity.py:149-222 on caller-owned dense s, r (mutated in place); returns nop. */
+int64_t oracle_similarity(int64_t n, const int64_t *indptr, const int32_t *indices, const double *data,
+                          const double *in_degree, int64_t seed, double rho, double epsilon,
+                          double *s, double *r)
+{
+    (void)n;
+    fifo_t q = {0, 0, 0, 0};
+    int64_t nop = similarity_core(indptr, indices, data, in_degree, seed, rho, epsilon, s, r, &q, 0, 0, 0);
+    free(q.buf);
+    return nop;
+}
+
+static int cmp_i32(const void *a, const void *b)
+{
+    int32_t x = *(const int32_t *)a, y = *(const int32_t *)b;
+    return (x > y) - (x < y);
+}
+
+/*
+ * arcte.py:337-376 for one seed on zeroed s, r.  Writes the emitted community
+ * (ascending node ids) to rows_out (capacity n) and returns its size, 0 when the
+ * reference emits nothing (:370), -1 on allocation failure, -2 when a member of
+ * the closed neighbourhood is missing from the support (the reference would
+ * mis-index at :359-360).  s, r are returned to all-zero.
+ */
+static int64_t seed_body(int64_t n, const int64_t *indptr, const int32_t *indices, const double *data,
+                         const double *out_degree, const double *in_degree, int64_t seed,
+                         double rho, double epsilon, double *s, double *r, fifo_t *q,
+                         int32_t *touched, double *nbr_deg, int32_t *rows_out,
+                         double *eps_out, int64_t *nop_out, oracle_stats_t *st)
+{
+    (void)n;
+    int64_t b = indptr[seed], e = indptr[seed + 1], deg = e - b;
+    for (int64_t k = 0; k < deg; k++) nbr_deg[k] = out_degree[indices[b + k]];            /* :340 */
+    double eps_eff = oracle_epsilon_effective(epsilon, out_degree[seed], nbr_deg, deg);
+    if (eps_out) *eps_out = eps_eff;
+    int64_t nt = 0;
+    int64_t nop = similarity_core(indptr, indices, data, in_degree, seed, rho, eps_eff, s, r, q,
+                                  touched, &nt, st);                                      /* :342-350 */
+    if (nop_out) *nop_out = nop;
+    int64_t result = 0;
+    if (nop < 0) result = -1;
+    else {
+        /* :352-360  s_norm = s / in_degree on the support; threshold = min over N[seed] + seed */
+        double thr = INFINITY;
+        int missing = 0;
+        for (int64_t k = b; k <= e; k++) {
+            int32_t v = (k < e) ? indices[k] : (int32_t)seed;
+            if (s[v] == 0.0) { missing = 1; break; }
+            double x = s[v] / in_degree[v];
+            if (x < thr) thr = x;
+        }
+        if (missing) result = -2;
+        else {
+            /* :363-367  count of support entries with s_norm >= thr (searchsorted side='left') */
+            int64_t k_sel = 0;
+            for (int64_t t = 0; t < nt; t++) {
+                int32_t v = touched[t];
+                if (s[v] / in_degree[v] >= thr) rows_out[k_sel++] = v;
+            }
+            if (k_sel > deg + 1) {                                                        /* :370 */
+                qsort(rows_out, (size_t)k_sel, sizeof(int32_t), cmp_i32);
+                result = k_sel;
+            }
+        }
+        if (st) st->support += nt;
+    }
+    for (int64_t t = 0; t < nt; t++) { s[touched[t]] = 0.0; r[touched[t]] = 0.0; }         /* :337-338 */
+    /* r can be non-zero only where s is (every deposit hits both; the seed is in the list) */
+    return result;
+}
+
+/*
+ * arcte.py:279-388 over a list of seeds.  Output is column-compressed: for seed k,
+ * rows[colptr[k] .. colptr[k+1]) are the members of its local community (empty when
+ * not emitted).  rows is malloc'ed here and handed back through *rows_io (caller frees
+ * with oracle_free).  eps_eff/nop/stats4 may be NULL.  stats4 = {pushes, edges,
+ * enqueues, support} summed over the seeds.  threads <= 1 runs single-threaded.
+ */
+int oracle_worker(int64_t n, const int64_t *indptr, const int32_t *indices, const double *data,
+                  const double *out_degree, const double *in_degree,
+                  const int64_t *seeds, int64_t nseeds, double rho, double epsilon, int threads,
+                  int64_t *colptr, int32_t **rows_io, double *eps_eff, int64_t *nop, int64_t *stats4)
+{
+    int64_t maxdeg = 0;
+    for (int64_t i = 0; i < n; i++) {
+        int64_t d = indptr[i + 1] - indptr[i];
+        if (d > maxdeg) maxdeg = d;
+    }
+    int32_t **seed_rows = (int32_t **)calloc((size_t)(nseeds > 0 ? nseeds : 1), sizeof(int32_t *));
+    int64_t *counts = (int64_t *)calloc((size_t)(nseeds > 0 ? nseeds : 1), sizeof(int64_t));
+    if (!seed_rows || !counts) return -1;
+    int status = 0;
+    oracle_stats_t total = {0, 0, 0, 0};
+#ifdef _OPENMP
+    if (threads < 1) threads = 1;
+#pragma omp parallel num_threads(threads)
+#endif
+    {
+        double *s = (double *)calloc((size_t)n, sizeof(double));
+        double *r = (double *)calloc((size_t)n, sizeof(double));
+        int32_t *touched = (int32_t *)malloc((size_t)(n + 1) * sizeof(int32_t));
+        int32_t *rows_tmp = (int32_t *)malloc((size_t)(n + 1) * sizeof(int32_t));
+        double *nbr_deg = (double *)malloc((size_t)(maxdeg + 1) * sizeof(double));
+        fifo_t q = {0, 0, 0, 0};
+        oracle_stats_t st = {0, 0, 0, 0};
+        int ok = s && r && touched && rows_tmp && nbr_deg;
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 4)
+#endif
+        for (int64_t k = 0; k < nseeds; k++) {
+            if (!ok) continue;
+            int64_t c = seed_body(n, indptr, indices, data, out_degree, in_degree, seeds[k], rho, epsilon,
+                                  s, r, &q, touched, nbr_deg, rows_tmp,
+                                  eps_eff ? eps_eff + k : 0, nop ? nop + k : 0, &st);
+            if (c < 0) {
+#ifdef _OPENMP
+#pragma omp critical
+#endif
+                status = (int)c;
+                continue;
+            }
+            counts[k] = c;
+            if (c > 0) {
+                seed_rows[k] = (int32_t *)malloc((size_t)c * sizeof(int32_t));
+                if (!seed_rows[k]) { ok = 0; continue; }
+                memcpy(seed_rows[k], rows_tmp, (size_t)c * sizeof(int32_t));
+            }
+        }
+#ifdef _OPENMP
+#pragma omp critical
+#endif
+        {
+            if (!ok) status = -1;
+            total.pushes += st.pushes; total.edges += st.edges;
+            total.enqueues += st.enqueues; total.support += st.support;
+        }
+        free(s); free(r); free(touched); free(rows_tmp); free(nbr_deg); free(q.buf);
+    }
+    colptr[0] = 0;
+    for (int64_t k = 0; k < nseeds; k++) colptr[k + 1] = colptr[k] + counts[k];
+    int32_t *rows = (int32_t *)malloc((size_t)(colptr[nseeds] > 0 ? colptr[nseeds] : 1) * sizeof(int32_t));
+    if (!rows) status = -1;
+    for (int64_t k = 0; k < nseeds; k++) {
+        if (rows && counts[k]) memcpy(rows + colptr[k], seed_rows[k], (size_t)counts[k] * sizeof(int32_t));
+        free(seed_rows[k]);
+    }
+    free(seed_rows);
+    free(counts);
+    *rows_io = rows;
+    if (stats4) { stats4[0] = total.pushes; stats4[1] = total.edges; stats4[2] = total.enqueues; stats4[3] = total.support; }
+    return status;
+}
+
+void oracle_free(void *p) { free(p); }
+
+int oracle_max_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}

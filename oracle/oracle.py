@@ -1,0 +1,169 @@
+"""ORACLE -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+ctypes front end of oracle/arcte_oracle.c plus numpy/scipy restatements of the two
+driver-level reference functions that are scipy calls rather than arithmetic:
+
+  eps_randomwalk/transition.py:43-68   -> get_natural_random_walk_matrix
+  embedding/arcte/arcte.py:591-688     -> arcte  (seed list :610-617, base block :676-683)
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this
+module.  Parity status: pinned by tests/golden/*.npz (outputs of the reference run in
+the build container, tests/golden/make_golden.py).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import scipy.sparse as sparse
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+_lib = None
+
+_f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+_i64p = np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")
+_i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "arcte_oracle.c")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.run(["make", "-C", _HERE, "-B", "liboracle.so"], check=True, capture_output=True)
+    return _LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        l = C.CDLL(_LIB_PATH)
+        l.oracle_np_sum.restype = C.c_double
+        l.oracle_np_sum.argtypes = [_f64p, C.c_int64]
+        l.oracle_epsilon_effective.restype = C.c_double
+        l.oracle_epsilon_effective.argtypes = [C.c_double, C.c_double, _f64p, C.c_int64]
+        l.oracle_push.restype = None
+        l.oracle_push.argtypes = [_f64p, _f64p, _f64p, _i32p, C.c_int64, C.c_int64, C.c_double]
+        l.oracle_similarity.restype = C.c_int64
+        l.oracle_similarity.argtypes = [C.c_int64, _i64p, _i32p, _f64p, _f64p, C.c_int64, C.c_double, C.c_double,
+                                        _f64p, _f64p]
+        l.oracle_worker.restype = C.c_int
+        l.oracle_worker.argtypes = [C.c_int64, _i64p, _i32p, _f64p, _f64p, _f64p, _i64p, C.c_int64,
+                                    C.c_double, C.c_double, C.c_int, _i64p, C.POINTER(C.POINTER(C.c_int32)),
+                                    C.c_void_p, C.c_void_p, C.c_void_p]
+        l.oracle_free.restype = None
+        l.oracle_free.argtypes = [C.c_void_p]
+        l.oracle_max_threads.restype = C.c_int
+        _lib = l
+    return _lib
+
+
+def _csr_arrays(w):
+    return (np.ascontiguousarray(w.indptr, dtype=np.int64),
+            np.ascontiguousarray(w.indices, dtype=np.int32),
+            np.ascontiguousarray(w.data, dtype=np.float64))
+
+
+def np_sum(a):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return lib().oracle_np_sum(a, a.size)
+
+
+def calculate_epsilon_effective(rho, epsilon, seed_degree, neighbor_degrees, mean_degree=None):
+    """arcte.py:26-50 (rho and mean_degree unused there as well)."""
+    nd = np.ascontiguousarray(neighbor_degrees, dtype=np.float64)
+    return lib().oracle_epsilon_effective(float(epsilon), float(seed_degree), nd, nd.size)
+
+
+def cumulative_pagerank_difference_limit_push(s, r, w_i, a_i, push_node, rho):
+    """push.py:41-64, in place on s, r."""
+    w_i = np.ascontiguousarray(w_i, dtype=np.float64)
+    a_i = np.ascontiguousarray(a_i, dtype=np.int32)
+    lib().oracle_push(s, r, w_i, a_i, a_i.size, int(push_node), float(rho))
+
+
+def similarity(w, in_degree, seed, rho, epsilon, s, r):
+    """similarity.py:149-222 on the CSR `w`; s, r dense float64, mutated in place; returns nop."""
+    indptr, indices, data = _csr_arrays(w)
+    return lib().oracle_similarity(w.shape[0], indptr, indices, data,
+                                   np.ascontiguousarray(in_degree, dtype=np.float64),
+                                   int(seed), float(rho), float(epsilon), s, r)
+
+
+def worker(w, out_degree, in_degree, seeds, rho, epsilon, threads=1, want_stats=False):
+    """arcte.py:279-388.  Returns (colptr[int64, nseeds+1], rows[int32]) and, with
+    want_stats, also (eps_eff, nop, stats4 = [pushes, edges, enqueues, support])."""
+    indptr, indices, data = _csr_arrays(w)
+    seeds = np.ascontiguousarray(seeds, dtype=np.int64)
+    n = w.shape[0]
+    colptr = np.zeros(seeds.size + 1, dtype=np.int64)
+    rows_p = C.POINTER(C.c_int32)()
+    eps_eff = np.zeros(seeds.size, dtype=np.float64)
+    nop = np.zeros(seeds.size, dtype=np.int64)
+    stats = np.zeros(4, dtype=np.int64)
+    rc = lib().oracle_worker(n, indptr, indices, data,
+                             np.ascontiguousarray(out_degree, dtype=np.float64),
+                             np.ascontiguousarray(in_degree, dtype=np.float64),
+                             seeds, seeds.size, float(rho), float(epsilon), int(threads),
+                             colptr, C.byref(rows_p),
+                             eps_eff.ctypes.data, nop.ctypes.data, stats.ctypes.data)
+    total = int(colptr[-1])
+    rows = np.ctypeslib.as_array(rows_p, shape=(max(total, 1),))[:total].copy()
+    lib().oracle_free(rows_p)
+    if rc != 0:
+        raise RuntimeError("oracle_worker failed with status %d" % rc)
+    if want_stats:
+        return colptr, rows, eps_eff, nop, stats
+    return colptr, rows
+
+
+def worker_matrix(w, out_degree, in_degree, seeds, rho, epsilon, threads=1):
+    """arcte_worker's return value: n x n CSR of ones, column = seed id (arcte.py:379-388)."""
+    n = w.shape[0]
+    seeds = np.asarray(seeds, dtype=np.int64)
+    colptr, rows = worker(w, out_degree, in_degree, seeds, rho, epsilon, threads)
+    cols = np.repeat(seeds, np.diff(colptr))
+    m = sparse.coo_matrix((np.ones(rows.size, dtype=np.float64), (rows.astype(np.int64), cols)), shape=(n, n))
+    return sparse.csr_matrix(m)
+
+
+def get_natural_random_walk_matrix(adjacency_matrix):
+    """transition.py:43-68 (make_shared only changes where the arrays live)."""
+    rw = sparse.csr_matrix(adjacency_matrix, dtype=np.float64, copy=True)          # :52
+    out_degree = rw.sum(axis=1)                                                     # :55
+    in_degree = rw.sum(axis=0)                                                      # :56
+    out_degree[out_degree == 0.0] = 1.0                                             # :58
+    od = np.asarray(out_degree).reshape(-1)
+    for i in range(rw.shape[0]):                                                    # :61-63
+        rw.data[rw.indptr[i]: rw.indptr[i + 1]] = rw.data[rw.indptr[i]: rw.indptr[i + 1]] / od[i]
+    rw.sort_indices()                                                               # :65
+    out_degree = np.array(out_degree).astype(np.float64).reshape(out_degree.size)   # :67
+    in_degree = np.array(in_degree).astype(np.float64).reshape(in_degree.size)      # :68
+    return rw, out_degree, in_degree
+
+
+def seed_list(adjacency_matrix):
+    """arcte.py:610-617: pattern in-count > 1, descending count (tie order is
+    unspecified in the reference -- unstable argsort -- and does not affect the output)."""
+    a = sparse.csr_matrix(adjacency_matrix).copy()
+    a.data = np.ones_like(a.data)
+    cnt = np.squeeze(np.asarray(a.sum(axis=0), dtype=np.int64)).reshape(-1)
+    nodes = np.where(cnt != 0)[0]
+    nodes = nodes[np.argsort(cnt[nodes], kind="stable")][::-1]
+    return nodes[cnt[nodes] > 1]
+
+
+def arcte(adjacency_matrix, rho, epsilon, number_of_threads=1):
+    """arcte.py:591-688.  Chunking over processes (:650-673) only partitions the
+    seed list and sums disjoint columns, so the thread count cannot change the result."""
+    adjacency_matrix = sparse.csr_matrix(adjacency_matrix)
+    n = adjacency_matrix.shape[0]
+    w, out_degree, in_degree = get_natural_random_walk_matrix(adjacency_matrix)
+    seeds = seed_list(adjacency_matrix)
+    local = worker_matrix(w, out_degree, in_degree, seeds, rho, epsilon, threads=number_of_threads)
+    identity = sparse.csr_matrix(sparse.eye(n, n, dtype=np.float64))               # :676
+    ones = adjacency_matrix.copy()
+    ones.data = np.ones_like(ones.data)                                             # :677-678
+    base = identity + ones                                                          # :679
+    return sparse.hstack([base, local]).tocsr()                                     # :683

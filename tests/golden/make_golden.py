@@ -1,0 +1,297 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by RUNNING THE REFERENCE.
+
+Runs only in the build container, where /root/reference is mounted read-only:
+
+    PYTHONDONTWRITEBYTECODE=1 PYTHONPATH=/root/reference python tests/golden/make_golden.py
+
+The reference has no tests or golden vectors of its own, so
+these files are the only pins for the oracle.  They hold DATA only: graphs that
+were fed to the reference and what the reference returned.  Nothing of the
+reference's source is stored.
+
+Fixture layout (one .npz per graph, see tests/test_oracle_golden.py for the reader):
+  adj_*            input adjacency (CSR, as handed to the reference)
+  w_*              get_natural_random_walk_matrix output (transition.py:43)
+  out_degree, in_degree
+  rho, epsilon
+  seeds            sampled seed ids
+  eps_eff          calculate_epsilon_effective per sampled seed (arcte.py:26)
+  nop              push count per sampled seed (similarity.py:149, effective eps)
+  s_ptr/s_idx/s_val, r_ptr/r_idx/r_val   support of s and r per sampled seed (raw float64)
+  raw_*            the same, run with the RAW epsilon instead of the effective one
+  push_*           one call of cumulative_pagerank_difference_limit_push (push.py:41)
+  feat1_*, feat3_* arcte() output (arcte.py:591) for number_of_threads 1 and 3
+  worker_*         arcte_worker() output for the sampled seeds (arcte.py:279)
+"""
+import hashlib
+import io
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import scipy.sparse as sparse
+import networkx as nx
+
+from reveal_graph_embedding.eps_randomwalk.transition import get_natural_random_walk_matrix
+from reveal_graph_embedding.eps_randomwalk.similarity import fast_approximate_cumulative_pagerank_difference
+from reveal_graph_embedding.eps_randomwalk.push import cumulative_pagerank_difference_limit_push
+from reveal_graph_embedding.embedding.arcte.arcte import arcte, arcte_worker, calculate_epsilon_effective
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+
+def csr_of_nx(g):
+    return sparse.csr_matrix(nx.to_scipy_sparse_array(g, dtype=np.float64, format="csr"))
+
+
+def block_diag_graphs(mats):
+    return sparse.csr_matrix(sparse.block_diag(mats, format="csr"), dtype=np.float64)
+
+
+def corner_graph():
+    star = csr_of_nx(nx.star_graph(10))
+    path = csr_of_nx(nx.path_graph(6))
+    clique = csr_of_nx(nx.complete_graph(5))
+    lollipop = csr_of_nx(nx.lollipop_graph(4, 3))
+    isolated = sparse.csr_matrix((3, 3), dtype=np.float64)
+    pair = csr_of_nx(nx.path_graph(2))
+    return block_diag_graphs([star, path, clique, isolated, lollipop, pair])
+
+
+def weighted_graph():
+    g = nx.barabasi_albert_graph(200, 3, seed=5)
+    a = sparse.triu(csr_of_nx(g), k=1).tocoo()
+    rng = np.random.default_rng(11)
+    w = rng.uniform(0.1, 5.0, size=a.nnz)
+    u = sparse.coo_matrix((w, (a.row, a.col)), shape=a.shape)
+    return sparse.csr_matrix(u + u.T)
+
+
+def selfloop_graph():
+    g = nx.barabasi_albert_graph(200, 2, seed=7)
+    a = csr_of_nx(g).tolil()
+    for i in (0, 3, 17, 42, 199):
+        a[i, i] = 1.0
+    return sparse.csr_matrix(a)
+
+
+def directed_graph():
+    rng = np.random.default_rng(13)
+    n = 300
+    rows, cols, vals = [], [], []
+    for i in range(n):
+        targets = rng.choice(n - 1, size=4, replace=False)
+        targets = targets + (targets >= i)
+        for t in targets:
+            rows.append(i)
+            cols.append(int(t))
+            vals.append(rng.uniform(0.5, 2.0))
+    return sparse.csr_matrix(sparse.coo_matrix((vals, (rows, cols)), shape=(n, n)))
+
+
+def rmat_small():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        "synthetic", os.path.join(os.path.dirname(os.path.dirname(HERE)), "reveal-graph-embedding_amd", "synthetic.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.rmat_graph(2000, 30000, seed=0), mod
+
+
+def graphs():
+    rm, _ = rmat_small()
+    return {
+        "ba300": (csr_of_nx(nx.barabasi_albert_graph(300, 3, seed=0)), 0.1, 1e-5),
+        "ba300_rho1e-3": (csr_of_nx(nx.barabasi_albert_graph(300, 3, seed=0)), 1e-3, 1e-5),
+        "ba1500": (csr_of_nx(nx.barabasi_albert_graph(1500, 4, seed=3)), 0.1, 1e-5),
+        "ws1000": (csr_of_nx(nx.watts_strogatz_graph(1000, 6, 0.1, seed=2)), 0.1, 1e-5),
+        "grid25": (csr_of_nx(nx.convert_node_labels_to_integers(nx.grid_2d_graph(25, 25))), 0.1, 1e-5),
+        "corner": (corner_graph(), 0.1, 1e-5),
+        "weighted": (weighted_graph(), 0.1, 1e-5),
+        "selfloop": (selfloop_graph(), 0.1, 1e-5),
+        "directed": (directed_graph(), 0.2, 1e-4),
+        "rmat2000": (rm, 0.1, 1e-5),
+    }
+
+
+def seed_list_of(adjacency):
+    """The reference's own seed ordering, evaluated by the reference's code path
+    (arcte.py:610-617) is not exposed as a function; arcte() output pins it
+    indirectly.  For sampling we only need 'pattern in-count > 1'."""
+    a = adjacency.copy()
+    a.data = np.ones_like(a.data)
+    cnt = np.squeeze(np.asarray(a.sum(axis=0), dtype=np.int64))
+    return np.where(cnt > 1)[0], cnt
+
+
+def pack_sparse_vectors(vectors):
+    ptr = [0]
+    idx = []
+    val = []
+    for v in vectors:
+        nz = np.nonzero(v)[0]
+        idx.append(nz.astype(np.int32))
+        val.append(v[nz].astype(np.float64))
+        ptr.append(ptr[-1] + nz.size)
+    return (np.array(ptr, dtype=np.int64),
+            np.concatenate(idx) if idx else np.zeros(0, np.int32),
+            np.concatenate(val) if val else np.zeros(0, np.float64))
+
+
+def canon(m):
+    m = sparse.csr_matrix(m).copy()
+    m.sum_duplicates()
+    m.sort_indices()
+    return m
+
+
+def run_graph(name, adjacency, rho, epsilon, n_sample=20):
+    adjacency = sparse.csr_matrix(adjacency, dtype=np.float64)
+    n = adjacency.shape[0]
+    out = {}
+    out["adj_indptr"] = adjacency.indptr.astype(np.int64)
+    out["adj_indices"] = adjacency.indices.astype(np.int32)
+    out["adj_data"] = adjacency.data.astype(np.float64)
+    out["n"] = np.int64(n)
+    out["rho"] = np.float64(rho)
+    out["epsilon"] = np.float64(epsilon)
+
+    w, out_degree, in_degree = get_natural_random_walk_matrix(adjacency, make_shared=False)
+    out["w_indptr"] = w.indptr.astype(np.int64)
+    out["w_indices"] = w.indices.astype(np.int32)
+    out["w_data"] = w.data.astype(np.float64)
+    out["out_degree"] = out_degree
+    out["in_degree"] = in_degree
+
+    cand, cnt = seed_list_of(adjacency)
+    rng = np.random.default_rng(1234)
+    order = cand[np.argsort(-cnt[cand], kind="stable")]
+    pick = list(order[:5]) + list(order[-3:])
+    rest = np.setdiff1d(cand, np.array(pick, dtype=np.int64))
+    if rest.size:
+        pick += list(rng.choice(rest, size=min(n_sample - len(pick), rest.size), replace=False))
+    seeds = np.array(sorted(set(int(p) for p in pick)), dtype=np.int64)
+    out["seeds"] = seeds
+
+    adjacent_nodes = np.ndarray(n, dtype=np.ndarray)
+    base_transitions = np.ndarray(n, dtype=np.ndarray)
+    for i in range(n):
+        adjacent_nodes[i] = w.indices[w.indptr[i]: w.indptr[i + 1]]
+        base_transitions[i] = w.data[w.indptr[i]: w.indptr[i + 1]]
+    mean_degree = np.mean(out_degree)
+
+    eps_eff = []
+    for flavour in ("eff", "raw"):
+        nops, svecs, rvecs = [], [], []
+        for sd in seeds:
+            s = np.zeros(n, dtype=np.float64)
+            r = np.zeros(n, dtype=np.float64)
+            if flavour == "eff":
+                e = calculate_epsilon_effective(rho, epsilon, out_degree[sd], out_degree[adjacent_nodes[sd]], mean_degree)
+                eps_eff.append(e)
+            else:
+                e = epsilon
+            nop = fast_approximate_cumulative_pagerank_difference(
+                s, r, base_transitions[:], adjacent_nodes[:], out_degree, in_degree, sd, rho, e)
+            nops.append(nop)
+            svecs.append(s)
+            rvecs.append(r)
+        pre = "" if flavour == "eff" else "raw_"
+        out[pre + "nop"] = np.array(nops, dtype=np.int64)
+        out[pre + "s_ptr"], out[pre + "s_idx"], out[pre + "s_val"] = pack_sparse_vectors(svecs)
+        out[pre + "r_ptr"], out[pre + "r_idx"], out[pre + "r_val"] = pack_sparse_vectors(rvecs)
+    out["eps_eff"] = np.array(eps_eff, dtype=np.float64)
+
+    # all-seed effective epsilon (pins calculate_epsilon_effective on every degree shape)
+    all_eps = np.zeros(cand.size, dtype=np.float64)
+    for k, sd in enumerate(cand):
+        all_eps[k] = calculate_epsilon_effective(rho, epsilon, out_degree[sd], out_degree[adjacent_nodes[sd]], mean_degree)
+    out["all_seeds"] = cand.astype(np.int64)
+    out["all_eps_eff"] = all_eps
+
+    # one isolated push from a non-trivial state (push.py:41)
+    rng2 = np.random.default_rng(99)
+    s0 = rng2.random(n)
+    r0 = rng2.random(n)
+    u = int(seeds[0])
+    s1, r1 = s0.copy(), r0.copy()
+    cumulative_pagerank_difference_limit_push(s1, r1, base_transitions[u], adjacent_nodes[u], u, rho)
+    out["push_node"] = np.int64(u)
+    out["push_s_in"], out["push_r_in"], out["push_s_out"], out["push_r_out"] = s0, r0, s1, r1
+
+    # arcte_worker on the sampled seeds
+    wf = canon(arcte_worker(seeds, w.indices, w.indptr, w.data, out_degree, in_degree, rho, epsilon))
+    out["worker_indptr"] = wf.indptr.astype(np.int64)
+    out["worker_indices"] = wf.indices.astype(np.int32)
+    out["worker_data"] = wf.data.astype(np.float64)
+
+    for threads in (1, 3):
+        f = canon(arcte(adjacency.copy(), rho, epsilon, threads))
+        assert f.shape == (n, 2 * n), f.shape
+        out["feat%d_indptr" % threads] = f.indptr.astype(np.int64)
+        out["feat%d_indices" % threads] = f.indices.astype(np.int32)
+        out["feat%d_data" % threads] = f.data.astype(np.float64)
+    same = (np.array_equal(out["feat1_indptr"], out["feat3_indptr"])
+            and np.array_equal(out["feat1_indices"], out["feat3_indices"]))
+    print("%-14s n=%5d nnz=%7d seeds=%5d feat_nnz=%8d  1-vs-3-threads identical=%s" % (
+        name, n, adjacency.nnz, cand.size, out["feat1_indices"].size, same))
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+
+
+def run_cli_fixture():
+    """a8: the reference console script on a tiny edge list (entry_points/arcte.py:12)."""
+    g = nx.barabasi_albert_graph(60, 2, seed=21)
+    rng = np.random.default_rng(3)
+    ids = rng.permutation(1000)[:60] + 100
+    lines = ["# tiny edge list\n"]
+    for (u, v) in g.edges():
+        lines.append("%d\t%d\t%.3f\n" % (ids[u], ids[v], rng.uniform(0.5, 2.0)))
+    text = "".join(lines)
+    with tempfile.TemporaryDirectory() as tmp:
+        inp = os.path.join(tmp, "edges.tsv")
+        outp = os.path.join(tmp, "features.tsv")
+        with open(inp, "w") as f:
+            f.write(text)
+        code = ("import sys; sys.argv=['arcte','-i',%r,'-o',%r,'-u','1','-nt','1'];"
+                "from reveal_graph_embedding.entry_points.arcte import main; main()") % (inp, outp)
+        env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
+        subprocess.run([sys.executable, "-c", code], check=True, env=env)
+        with open(outp) as f:
+            result = f.read()
+    with open(os.path.join(HERE, "cli_edges.tsv"), "w") as f:
+        f.write(text)
+    with open(os.path.join(HERE, "cli_features_expected.tsv"), "w") as f:
+        f.write(result)
+    print("cli fixture: %d input lines, %d output lines" % (len(lines), result.count("\n")))
+
+
+def run_config1_hash():
+    """Full-size spot check: arcte() on the config-1 R-MAT graph, 8 processes."""
+    _, mod = rmat_small()
+    adjacency = mod.rmat_graph(100000, 2000000, seed=0)
+    f = canon(arcte(adjacency.copy(), 0.1, 1e-5, 8))
+    h = hashlib.sha256()
+    h.update(f.indptr.astype(np.int64).tobytes())
+    h.update(f.indices.astype(np.int64).tobytes())
+    local = sparse.csc_matrix(f[:, 100000:])
+    col_counts = np.diff(local.indptr).astype(np.int32)
+    np.savez_compressed(os.path.join(HERE, "rmat100k_summary.npz"),
+                        sha256=np.frombuffer(h.digest(), dtype=np.uint8),
+                        nnz=np.int64(f.nnz), local_col_counts=col_counts,
+                        rho=np.float64(0.1), epsilon=np.float64(1e-5))
+    print("config-1 R-MAT: feature nnz", f.nnz, "sha256", h.hexdigest())
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["small", "cli"]
+    if "small" in which:
+        for name, (adj, rho, eps) in graphs().items():
+            run_graph(name, adj, rho, eps)
+    if "cli" in which:
+        run_cli_fixture()
+    if "config1" in which:
+        run_config1_hash()
