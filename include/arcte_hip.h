@@ -1,0 +1,139 @@
+/*
+ * arcte_hip.h -- C ABI of the MI355X (gfx950) ARCTE hot path.
+ *
+ * The reference (MKLab-ITI/reveal-graph-embedding) has no FFI of its own for this
+ * path: its native seam is the flat-array signature of arcte_worker().  Every entry
+ * point below names the reference interface it replaces (paths relative to
+ * reveal_graph_embedding/ in the reference tree).  INTEGRATION.md shows the ctypes
+ * stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative ARCTE_HIP_E* code otherwise;
+ *     arcte_hip_last_error() then holds a message (thread-local, never NULL);
+ *   - host arrays are borrowed for the duration of the call only; device memory
+ *     belongs to the context; no exceptions cross the boundary;
+ *   - one context per GPU, calls on one context must be serialised by the caller;
+ *   - node ids are int32 (n < 2^31), CSR row pointers int64, values float64;
+ *   - there is NO CPU fallback: without a HIP device every compute entry fails.
+ */
+#ifndef ARCTE_HIP_H
+#define ARCTE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ARCTE_HIP_OK 0
+#define ARCTE_HIP_EINVAL (-1)   /* bad argument */
+#define ARCTE_HIP_EHIP (-2)     /* a HIP runtime call failed (no device, out of memory, ...) */
+#define ARCTE_HIP_ECAPACITY (-3) /* a seed did not fit the queue/output capacity even after growing */
+#define ARCTE_HIP_ESTATE (-4)   /* call order (e.g. fetch before run) */
+#define ARCTE_HIP_EGRAPH (-5)   /* input the reference itself cannot process (see arcte_hip_run_seeds) */
+
+typedef struct arcte_hip_ctx arcte_hip_ctx;
+
+/* Version of this ABI (bumped on any signature change). */
+int arcte_hip_abi_version(void);
+
+/* Message of the last failing call on this thread. */
+const char *arcte_hip_last_error(void);
+
+/* Number of visible HIP devices (0 on a machine without a GPU; does not initialise one). */
+int arcte_hip_device_count(int *count);
+
+/*
+ * Upload the random-walk transition matrix to `device` and allocate the per-wavefront
+ * propagation slots.  Inputs are exactly what get_natural_random_walk_matrix returns
+ * (eps_randomwalk/transition.py:43-99) and what arcte_worker receives
+ * (embedding/arcte/arcte.py:279-286): CSR (indptr[n+1], indices[nnz] ascending inside a
+ * row, data[nnz]) of W = D_out^-1 A, weighted out_degree[n], in_degree[n].
+ * n_slots = 0 picks one slot per resident wavefront; queue_capacity = 0 picks
+ * max(n, 4096) rounded up to a power of two (the FIFO of similarity.py:180 is
+ * unbounded; an overflowing seed is re-run with a larger ring, never dropped).
+ */
+int arcte_hip_create(int device, int64_t n, int64_t nnz,
+                     const int64_t *indptr, const int32_t *indices, const double *data,
+                     const double *out_degree, const double *in_degree,
+                     int64_t n_slots, int64_t queue_capacity, arcte_hip_ctx **out);
+
+int arcte_hip_destroy(arcte_hip_ctx *ctx);
+
+/*
+ * calculate_epsilon_effective (embedding/arcte/arcte.py:26-50) for each seed, with the
+ * seed's weighted out-degree and its neighbours' out-degrees as at arcte.py:340.
+ * The neighbour mean uses numpy's pairwise summation order.
+ */
+int arcte_hip_epsilon_effective(arcte_hip_ctx *ctx, const int64_t *seeds, int64_t nseeds,
+                                double epsilon, double *eps_out);
+
+/*
+ * The loop body of arcte_worker (embedding/arcte/arcte.py:337-376) for every seed:
+ * effective epsilon -> fast_approximate_cumulative_pagerank_difference
+ * (eps_randomwalk/similarity.py:149-222, pushes of eps_randomwalk/push.py:41-64) ->
+ * degree normalisation -> threshold select -> emit.  use_effective_epsilon = 0 feeds the
+ * raw `epsilon` to every seed instead (the older cython_opt driver's behaviour).
+ * Results stay on the device until fetched.  A seed whose closed neighbourhood is not
+ * contained in its support (zero-weight edges; the reference mis-indexes there,
+ * arcte.py:359-360) fails the call with ARCTE_HIP_EGRAPH.
+ */
+int arcte_hip_run_seeds(arcte_hip_ctx *ctx, const int64_t *seeds, int64_t nseeds,
+                        double rho, double epsilon, int use_effective_epsilon);
+
+/* Sizes of the last run: number of seeds and total emitted (row, seed) pairs. */
+int arcte_hip_result_sizes(arcte_hip_ctx *ctx, int64_t *nseeds, int64_t *total_rows);
+
+/*
+ * Copy the last run to the host in column-compressed form: rows[colptr[k] .. colptr[k+1])
+ * are the members of seed k's local community (empty when the reference emits nothing,
+ * arcte.py:370).  Any of the output pointers may be NULL.  eps_used[k] is the threshold
+ * the seed ran with, nop[k] the return value of
+ * fast_approximate_cumulative_pagerank_difference.
+ */
+int arcte_hip_fetch_result(arcte_hip_ctx *ctx, int64_t *colptr, int32_t *rows,
+                           double *eps_used, int64_t *nop);
+
+/* Device addresses of the last run's rows (int32[total_rows]) for a device-side gather
+ * (RCCL); valid until the next run on this context. */
+int arcte_hip_result_device_rows(arcte_hip_ctx *ctx, void **rows_dev);
+
+/*
+ * Work counters of the last run, summed over its seeds:
+ * stats[0] pushes, [1] edges traversed, [2] enqueues, [3] support entries,
+ * [4] seed re-runs after a queue/output overflow, [5] kernel launches.
+ */
+int arcte_hip_run_stats(arcte_hip_ctx *ctx, int64_t stats[6]);
+
+/*
+ * Device time of the last run in milliseconds, from HIP events recorded on the
+ * context's stream: ms[0] effective-epsilon kernel, [1] push/extract kernel(s),
+ * [2] compaction, [3] whole call (host wall clock, includes the small host scans).
+ */
+int arcte_hip_run_timing(arcte_hip_ctx *ctx, double ms[4]);
+
+/*
+ * fast_approximate_cumulative_pagerank_difference (eps_randomwalk/similarity.py:149-222)
+ * on caller-owned dense s[n], r[n]: both are uploaded as they are, the seed entries are
+ * set to 1, the propagation runs with the raw `epsilon`, and both are written back.
+ * *nop receives the number of pushes.
+ */
+int arcte_hip_similarity_slice(arcte_hip_ctx *ctx, int64_t seed, double rho, double epsilon,
+                               double *s, double *r, int64_t *nop);
+
+/*
+ * cumulative_pagerank_difference_limit_push (eps_randomwalk/push.py:41-64): one push of
+ * `push_node` over (w_i, a_i) on caller-owned dense s[n], r[n].  Context-free.
+ */
+int arcte_hip_push(int device, int64_t n, double *s, double *r,
+                   const double *w_i, const int32_t *a_i, int64_t deg,
+                   int64_t push_node, double rho);
+
+/* Properties of the context: info[0] slots, [1] queue capacity, [2] device bytes held,
+ * [3] compute units, [4] wavefronts per workgroup. */
+int arcte_hip_info(arcte_hip_ctx *ctx, int64_t info[5]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ARCTE_HIP_H */

@@ -1,0 +1,1165 @@
+// ARCTE eps-truncated absorbing-random-walk propagation for MI355X (gfx950 / CDNA4).
+//
+// One 64-lane wavefront owns one seed at a time ("slot"): it runs the reference's strictly
+// sequential FIFO of similarity.py:149-222 exactly, and spends its 64 lanes on the edges of
+// the row being pushed (push.py:62-64: distinct targets, no conflicts).  Thousands of slots
+// are in flight per GPU, each with a private dense {r, s} vector in HBM, so the chip is kept
+// busy by seed-level parallelism while every seed keeps the reference's operation order --
+// which is what makes the output sparsity pattern bit-exact.
+//
+// Arithmetic notes (all pinned by tests against the CPU oracle):
+//   - built with -ffp-contract=off: p = c*w then s+p, r+p are separate IEEE operations as in
+//     push.py:62-64, never an FMA;
+//   - thresholds use true IEEE division r/in_degree >= eps (similarity.py:204,214);
+//   - the neighbour-degree mean of calculate_epsilon_effective follows numpy's pairwise order.
+//
+// C ABI: include/arcte_hip.h.  No CPU fallback lives here.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "arcte_hip.h"
+
+// ---------------------------------------------------------------------------------------------
+// device helpers (wave64)
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+constexpr int WAVE = 64;
+constexpr int WAVES_PER_BLOCK = 4;
+constexpr int BLOCK = WAVE * WAVES_PER_BLOCK;
+
+enum SeedStatus : int32_t {
+    ST_OK = 0,
+    ST_QUEUE_OVERFLOW = 1,
+    ST_OUTPUT_OVERFLOW = 2,
+    ST_MISSING_BASE = 3,
+    ST_RUNAWAY = 4,   // push cap hit: every wave must reach an exit (guards against a non-converging input)
+};
+
+__device__ __forceinline__ int lane_below(uint64_t m)
+{
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+}
+
+__device__ __forceinline__ uint64_t bcast_u64(uint64_t v)
+{
+    uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+    uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+
+
+__device__ __forceinline__ double shfl_f64(double v, int src) { return __shfl(v, src, WAVE); }
+__device__ __forceinline__ int64_t shfl_i64(int64_t v, int src)
+{
+    int lo = __shfl((int)(uint32_t)v, src, WAVE);
+    int hi = __shfl((int)(uint32_t)((uint64_t)v >> 32), src, WAVE);
+    return (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
+}
+
+__device__ __forceinline__ double wave_min(double x)
+{
+    for (int o = 32; o > 0; o >>= 1) {
+        double y = __shfl_xor(x, o, WAVE);
+        x = (y < x) ? y : x;
+    }
+    return x;
+}
+__device__ __forceinline__ double wave_max(double x)
+{
+    for (int o = 32; o > 0; o >>= 1) {
+        double y = __shfl_xor(x, o, WAVE);
+        x = (y > x) ? y : x;
+    }
+    return x;
+}
+
+struct GraphDev {
+    int64_t n;
+    const int64_t *indptr;
+    const int32_t *indices;
+    const double *data;
+    const double *out_degree;
+    const double *in_degree;
+};
+
+// ---------------------------------------------------------------------------------------------
+// a4: calculate_epsilon_effective (arcte.py:26-50), one wavefront per seed
+// ---------------------------------------------------------------------------------------------
+
+struct PwFrame {
+    int64_t lo;
+    int64_t n;
+    double left;
+    int32_t stage;
+    int32_t pad;
+};
+
+struct EpsShared {
+    double leaf[128];
+    PwFrame frames[40];
+};
+
+// numpy pairwise leaf (n <= 128) over a[i] = out_degree[indices[lo + i]]; also folds min/max of a.
+__device__ double pw_leaf(const GraphDev &g, int64_t lo, int64_t n, double *leaf, int lane, double &amin, double &amax)
+{
+    for (int i = lane; i < n; i += WAVE) {
+        double a = g.out_degree[g.indices[lo + i]];
+        leaf[i] = a;
+        amin = (a < amin) ? a : amin;
+        amax = (a > amax) ? a : amax;
+    }
+    // same-wave LDS write -> read: the DS queue is in order, the compiler keeps the dependency
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    double res;
+    if (n < 8) {
+        res = 0.0;
+        for (int i = 0; i < n; i++) res += leaf[i];
+    } else {
+        int64_t nfull = n - (n % 8);
+        double r = 0.0;
+        if (lane < 8) {
+            r = leaf[lane];
+            for (int64_t i = 8 + lane; i < nfull; i += 8) r += leaf[i];
+        }
+        double r0 = shfl_f64(r, 0), r1 = shfl_f64(r, 1), r2 = shfl_f64(r, 2), r3 = shfl_f64(r, 3);
+        double r4 = shfl_f64(r, 4), r5 = shfl_f64(r, 5), r6 = shfl_f64(r, 6), r7 = shfl_f64(r, 7);
+        res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+        for (int64_t i = nfull; i < n; i++) res += leaf[i];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    return res;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_epsilon_effective(GraphDev g, const int32_t *seeds, int64_t nseeds,
+                                                             double epsilon, double *eps_out)
+{
+    __shared__ EpsShared sh[WAVES_PER_BLOCK];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    EpsShared &S = sh[wave];
+    const int64_t k = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wave;
+    if (k >= nseeds) return;
+    const int32_t seed = seeds[k];
+    const int64_t b = g.indptr[seed];
+    const int64_t m = g.indptr[seed + 1] - b;
+    const double ds = g.out_degree[seed];
+    double amin = INFINITY, amax = -INFINITY;
+
+    // pairwise recursion of numpy's float64 add.reduce, evaluated with an explicit frame stack
+    int sp = 0;
+    double ret = 0.0;
+    if (lane == 0) { S.frames[0].lo = b; S.frames[0].n = m; S.frames[0].stage = 0; }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    while (sp >= 0) {
+        const int64_t flo = S.frames[sp].lo;
+        const int64_t fn = S.frames[sp].n;
+        const int stage = S.frames[sp].stage;
+        if (fn <= 128) {
+            ret = pw_leaf(g, flo, fn, S.leaf, lane, amin, amax);
+            sp--;
+            continue;
+        }
+        int64_t n2 = fn / 2;
+        n2 -= n2 % 8;
+        if (stage == 0) {
+            if (lane == 0) {
+                S.frames[sp].stage = 1;
+                S.frames[sp + 1].lo = flo; S.frames[sp + 1].n = n2; S.frames[sp + 1].stage = 0;
+            }
+            sp++;
+        } else if (stage == 1) {
+            if (lane == 0) {
+                S.frames[sp].left = ret;
+                S.frames[sp].stage = 2;
+                S.frames[sp + 1].lo = flo + n2; S.frames[sp + 1].n = fn - n2; S.frames[sp + 1].stage = 0;
+            }
+            sp++;
+        } else {
+            ret = S.frames[sp].left + ret;
+            sp--;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    }
+    amin = wave_min(amin);
+    amax = wave_max(amax);
+    if (lane == 0) {
+        double mean = ret / (double)m;                                            // arcte.py:32
+        double e = (epsilon * log(1 + ds)) / log(1 + mean);                       // :35
+        // :39-40  max/min over i of 1/(ds*a_i): correctly rounded * and / are monotone, so the
+        // extrema sit at the extrema of a_i
+        double emax = 1 / (ds * amin);
+        double emin = 1 / (ds * amax);
+        if (m == 0) { emax = -INFINITY; emin = INFINITY; }
+        if (e > emax) e = emax;                                                   // :45-48
+        else if (e < emin) e = (emin + e) / 2;
+        eps_out[k] = e;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// a2 + a3 + a5: per-seed FIFO propagation and community extraction
+// ---------------------------------------------------------------------------------------------
+
+struct PushParams {
+    GraphDev g;
+    // work list
+    const int32_t *work_pos;   // positions into seeds/eps/out arrays for this launch (NULL = identity)
+    int64_t nwork;
+    unsigned long long *work_counter;
+    const int32_t *seeds;
+    const double *eps;
+    double one_minus_rho;
+    // per-slot scratch
+    double2 *rs;       // [slots][n]  {x = r, y = s}
+    int32_t *queue;    // [slots][qcap]
+    int32_t *sup;      // [slots][n]   first-touch list = support of s
+    uint32_t qcap;     // power of two
+    int32_t max_pushes; // per-seed cap, see ST_RUNAWAY
+    // outputs
+    int32_t *raw;      // raw row arena, allocation order
+    unsigned long long rawcap;
+    unsigned long long *raw_cursor;
+    int64_t *out_off;
+    int32_t *out_cnt;
+    int32_t *status;
+    int32_t *nop;
+    unsigned long long *stats;   // [0] pushes [1] edges [2] enqueues [3] support [4] failed seeds
+};
+
+// MODE 0: full arcte_worker body (extract + reset).  MODE 1: similarity slice only, the slot's
+// dense vectors are left for the host to read back.
+template <int MODE>
+__global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int64_t slot = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wave;
+    const GraphDev &g = P.g;
+    double2 *__restrict__ rs = P.rs + slot * g.n;
+    int32_t *__restrict__ q = P.queue + slot * (int64_t)P.qcap;
+    int32_t *__restrict__ sup = P.sup + slot * g.n;
+    const uint32_t qmask = P.qcap - 1;
+    const double omr = P.one_minus_rho;
+
+    // Dynamic seed queue: lane 0 draws the next work item, the wave broadcasts it.  The
+    // wave_barrier (convergent, emits nothing) keeps LLVM's jump threading from fusing this
+    // lane-0 block with the lane-0 block that ends the previous iteration -- that fusion turned the
+    // loop divergent (lanes 1..63 ran ahead without lane 0 and never left it).
+    auto next_work = [&]() -> unsigned long long {
+        __builtin_amdgcn_wave_barrier();
+        unsigned long long w = 0;
+        if (lane == 0) w = atomicAdd(P.work_counter, 1ULL);
+        return bcast_u64(w);
+    };
+    for (unsigned long long wk = next_work(); wk < (unsigned long long)P.nwork; wk = next_work()) {
+        const int32_t pos = P.work_pos ? P.work_pos[wk] : (int32_t)wk;
+        const int32_t seed = P.seeds[pos];
+        const double eps = P.eps[pos];
+        if (MODE == 0) {
+            // the arena is already full: this seed is re-run by the host after the arena is drained
+            unsigned long long cur = 0;
+            if (lane == 0) cur = __hip_atomic_load(P.raw_cursor, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            cur = bcast_u64(cur);
+            if (cur > P.rawcap) {
+                if (lane == 0) {
+                    P.status[pos] = ST_OUTPUT_OVERFLOW;
+                    P.out_cnt[pos] = 0;
+                    P.out_off[pos] = 0;
+                    P.nop[pos] = 0;
+                    atomicAdd(&P.stats[4], 1ULL);
+                }
+                continue;
+            }
+        }
+
+        uint32_t head = 0, tail = 0;       // ring counters (wave-uniform)
+        int32_t nsup = 0;
+        int32_t npush = 0;
+        unsigned long long nedges = 0;
+        bool ok = true, runaway = false;
+
+        // ---- one push of node u (push.py:41-64) followed by the ordered enqueue of
+        //      similarity.py:194-196 / :214-216.  `ru` is r[u] at pop time.
+        auto push = [&](int32_t u, double ru, int64_t rb, int64_t re) {
+            const double c = omr * ru;                       // push.py:56
+            if (lane == 0) rs[u].x = 0.0;                    // push.py:59
+            for (int64_t base = rb; base < re; base += 2 * WAVE) {
+                const int64_t k0 = base + lane, k1 = k0 + WAVE;
+                const bool a0 = k0 < re, a1 = k1 < re;
+                int32_t v0 = 0, v1 = 0;
+                double w0 = 0.0, w1 = 0.0;
+                if (a0) { v0 = g.indices[k0]; w0 = g.data[k0]; }
+                if (a1) { v1 = g.indices[k1]; w1 = g.data[k1]; }
+                double2 g0 = make_double2(0.0, 0.0), g1 = make_double2(0.0, 0.0);
+                double d0 = 1.0, d1 = 1.0;
+                if (a0) { g0 = rs[v0]; d0 = g.in_degree[v0]; }
+                if (a1) { g1 = rs[v1]; d1 = g.in_degree[v1]; }
+#pragma unroll
+                for (int t = 0; t < 2; t++) {
+                    const bool act = t ? a1 : a0;
+                    const int32_t v = t ? v1 : v0;
+                    const double w = t ? w1 : w0;
+                    const double2 gv = t ? g1 : g0;
+                    const double dv = t ? d1 : d0;
+                    const double p = c * w;                                  // push.py:62
+                    const double r_old = (v == u) ? 0.0 : gv.x;              // self-loop sees r[u] = 0
+                    const double r_new = r_old + p;                          // push.py:64
+                    const double s_new = gv.y + p;                           // push.py:63
+                    if (act) rs[v] = make_double2(r_new, s_new);
+                    const bool first = act && gv.y == 0.0 && s_new != 0.0;   // support grows
+                    const uint64_t mf = __ballot(first);
+                    if (first) sup[nsup + lane_below(mf)] = v;
+                    nsup += __popcll(mf);
+                    const bool enq = act && (r_new / dv >= eps);             // similarity.py:194/214
+                    const uint64_t me = __ballot(enq);
+                    const uint32_t cnt = __popcll(me);
+                    if (cnt) {
+                        if (tail - head + cnt > P.qcap) { ok = false; }
+                        else {
+                            if (enq) q[(tail + lane_below(me)) & qmask] = v;
+                            tail += cnt;
+                        }
+                    }
+                }
+                if (!ok) break;
+            }
+            npush++;
+            nedges += (unsigned long long)(re - rb);
+            if (npush >= P.max_pushes) { ok = false; runaway = true; }
+        };
+
+        // ---- similarity.py:176-192: s[seed] = r[seed] = 1, one unconditional push
+        if (lane == 0) {
+            rs[seed] = make_double2(1.0, 1.0);
+            sup[0] = seed;
+        }
+        nsup = 1;
+        push(seed, 1.0, g.indptr[seed], g.indptr[seed + 1]);
+
+        // ---- similarity.py:199-216: FIFO with duplicates.  Up to 64 queue entries are taken per
+        //      batch; r/in_degree of all of them is tested in parallel and the first passing entry
+        //      (in FIFO order) is pushed; entries before it are no-op pops.  r of the not yet
+        //      consumed entries is re-read after every push, so every test sees r at its pop time.
+        while (ok && head != tail) {
+            const uint32_t navail = tail - head;
+            const uint32_t bn = navail < (uint32_t)WAVE ? navail : (uint32_t)WAVE;
+            const bool valid = (uint32_t)lane < bn;
+            int32_t u_l = 0;
+            double r_l = 0.0, d_l = 1.0;
+            int64_t rb_l = 0, re_l = 0;
+            if (valid) {
+                u_l = q[(head + lane) & qmask];
+                r_l = rs[u_l].x;
+                d_l = g.in_degree[u_l];
+                rb_l = g.indptr[u_l];
+                re_l = g.indptr[u_l + 1];
+            }
+            head += bn;    // the batch lives in registers from here on
+            int consumed = 0;
+            for (;;) {
+                const bool pass = valid && lane >= consumed && (r_l / d_l >= eps);   // similarity.py:204
+                const uint64_t m = __ballot(pass);
+                if (m == 0) break;
+                const int i = __ffsll((unsigned long long)m) - 1;
+                const int32_t u = __shfl(u_l, i, WAVE);
+                const double ru = shfl_f64(r_l, i);
+                const int64_t rb = shfl_i64(rb_l, i);
+                const int64_t re = shfl_i64(re_l, i);
+                consumed = i + 1;
+                push(u, ru, rb, re);
+                if (!ok) break;
+                if (valid && lane >= consumed) r_l = rs[u_l].x;
+            }
+        }
+
+        // ---- arcte.py:352-376: degree-normalise, threshold = min over the closed neighbourhood,
+        //      select everything at or above it, emit iff larger than the base community
+        int32_t st = ok ? ST_OK : (runaway ? ST_RUNAWAY : ST_QUEUE_OVERFLOW);
+        int32_t emitted = 0;
+        unsigned long long off = 0;
+        if (MODE == 0 && ok) {
+            const int64_t sb = g.indptr[seed], se = g.indptr[seed + 1];
+            double thr = rs[seed].y / g.in_degree[seed];
+            bool miss = false;
+            for (int64_t k = sb + lane; k < se; k += WAVE) {
+                const int32_t v = g.indices[k];
+                const double sv = rs[v].y;
+                miss |= (sv == 0.0);
+                const double x = sv / g.in_degree[v];
+                thr = (x < thr) ? x : thr;
+            }
+            thr = wave_min(thr);
+            if (__ballot(miss) != 0) st = ST_MISSING_BASE;
+            else {
+                int32_t cnt = 0;
+                for (int32_t i0 = 0; i0 < nsup; i0 += WAVE) {
+                    const int32_t i = i0 + lane;
+                    bool sel = false;
+                    if (i < nsup) {
+                        const int32_t v = sup[i];
+                        sel = (rs[v].y / g.in_degree[v]) >= thr;
+                    }
+                    cnt += __popcll(__ballot(sel));
+                }
+                if ((int64_t)cnt > (se - sb) + 1) {                                   // arcte.py:370
+                    if (lane == 0) off = atomicAdd(P.raw_cursor, (unsigned long long)cnt);
+                    off = bcast_u64(off);
+                    if (off + (unsigned long long)cnt > P.rawcap) st = ST_OUTPUT_OVERFLOW;
+                    else {
+                        int32_t w = 0;
+                        for (int32_t i0 = 0; i0 < nsup; i0 += WAVE) {
+                            const int32_t i = i0 + lane;
+                            bool sel = false;
+                            int32_t v = 0;
+                            if (i < nsup) {
+                                v = sup[i];
+                                sel = (rs[v].y / g.in_degree[v]) >= thr;
+                            }
+                            const uint64_t ms = __ballot(sel);
+                            if (sel) P.raw[off + w + lane_below(ms)] = v;
+                            w += __popcll(ms);
+                        }
+                        emitted = cnt;
+                    }
+                }
+            }
+        }
+        if (MODE == 0) {
+            // arcte.py:337-338 (s[:] = 0, r[:] = 0) restricted to what was touched
+            for (int32_t i = lane; i < nsup; i += WAVE) rs[sup[i]] = make_double2(0.0, 0.0);
+        }
+        if (lane == 0) {
+            P.status[pos] = st;
+            P.out_cnt[pos] = emitted;
+            P.out_off[pos] = (int64_t)off;
+            P.nop[pos] = npush;
+            if (st == ST_OK) {
+                atomicAdd(&P.stats[0], (unsigned long long)npush);
+                atomicAdd(&P.stats[1], nedges);
+                atomicAdd(&P.stats[2], (unsigned long long)tail);
+                atomicAdd(&P.stats[3], (unsigned long long)nsup);
+            } else {
+                atomicAdd(&P.stats[4], 1ULL);
+            }
+        }
+    }
+}
+
+// copy per-seed segments src[src_off[p] .. +cnt[p]) -> dst[dst_off[p] ..), one wavefront per segment;
+// p = work_pos[k] (identity when NULL)
+__global__ __launch_bounds__(BLOCK) void k_gather_segments(const int32_t *src, const int64_t *src_off, const int32_t *cnt,
+                                                           const int64_t *dst_off, int32_t *dst, const int32_t *work_pos,
+                                                           int64_t nseg)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t k = (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (k >= nseg) return;
+    const int64_t p = work_pos ? work_pos[k] : k;
+    const int32_t c = cnt[p];
+    const int32_t *s = src + src_off[p];
+    int32_t *d = dst + dst_off[p];
+    for (int32_t i = lane; i < c; i += WAVE) d[i] = s[i];
+}
+
+__global__ void k_interleave(const double *s, const double *r, double2 *rs, int64_t n)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) rs[i] = make_double2(r[i], s[i]);
+}
+
+__global__ void k_deinterleave(const double2 *rs, double *s, double *r, int64_t n)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { double2 v = rs[i]; r[i] = v.x; s[i] = v.y; }
+}
+
+// push.py:41-64 on dense device vectors, one workgroup
+__global__ __launch_bounds__(BLOCK) void k_single_push(double *s, double *r, const double *w_i, const int32_t *a_i,
+                                                       int64_t deg, int64_t push_node, double one_minus_rho)
+{
+    __shared__ double commute;
+    if (threadIdx.x == 0) {
+        commute = one_minus_rho * r[push_node];
+        r[push_node] = 0.0;
+    }
+    __syncthreads();
+    __threadfence_block();
+    const double c = commute;
+    for (int64_t k = threadIdx.x; k < deg; k += BLOCK) {
+        const int32_t v = a_i[k];
+        const double p = c * w_i[k];
+        s[v] += p;
+        r[v] += p;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+
+thread_local std::string g_err = "";
+
+int fail(int code, const std::string &msg)
+{
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(ARCTE_HIP_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_));         \
+    } while (0)
+
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t count = 0;
+    hipError_t alloc(size_t c)
+    {
+        release();
+        count = c;
+        return hipMalloc((void **)&p, std::max<size_t>(c, 1) * sizeof(T));
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        count = 0;
+    }
+    size_t bytes() const { return count * sizeof(T); }
+};
+
+int32_t max_pushes_limit()
+{
+    if (const char *env = getenv("ARCTE_HIP_MAX_PUSHES")) {
+        long long v = atoll(env);
+        if (v > 0 && v < (1ll << 31)) return (int32_t)v;
+    }
+    return 1 << 26;
+}
+
+uint32_t next_pow2(uint64_t x)
+{
+    uint64_t p = 1;
+    while (p < x) p <<= 1;
+    return (uint32_t)std::min<uint64_t>(p, 1ull << 31);
+}
+
+}  // namespace
+
+struct arcte_hip_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[6] = {};
+    int cus = 0;
+    int64_t n = 0, nnz = 0;
+    DevBuf<int64_t> indptr;
+    DevBuf<int32_t> indices;
+    DevBuf<double> data, out_degree, in_degree;
+    // slots
+    int64_t slots = 0;
+    uint32_t qcap = 0;
+    DevBuf<double2> rs;
+    DevBuf<int32_t> queue, sup;
+    // per-run
+    int64_t run_nseeds = -1;
+    DevBuf<int32_t> seeds_d, work_pos, out_cnt, status, nop_d;
+    DevBuf<double> eps_d;
+    DevBuf<int64_t> out_off, dst_off;
+    DevBuf<unsigned long long> counters;   // [0] work counter [1] raw cursor [2..6] stats
+    DevBuf<int32_t> raw, rows_final;
+    int64_t final_rows = 0;
+    std::vector<int64_t> colptr;
+    int64_t stats[6] = {0, 0, 0, 0, 0, 0};
+    double ms[4] = {0, 0, 0, 0};
+
+    GraphDev graph() const
+    {
+        GraphDev g;
+        g.n = n;
+        g.indptr = indptr.p;
+        g.indices = indices.p;
+        g.data = data.p;
+        g.out_degree = out_degree.p;
+        g.in_degree = in_degree.p;
+        return g;
+    }
+    size_t device_bytes() const
+    {
+        return indptr.bytes() + indices.bytes() + data.bytes() + out_degree.bytes() + in_degree.bytes() + rs.bytes() +
+               queue.bytes() + sup.bytes() + seeds_d.bytes() + work_pos.bytes() + out_cnt.bytes() + status.bytes() +
+               nop_d.bytes() + eps_d.bytes() + out_off.bytes() + dst_off.bytes() + raw.bytes() + rows_final.bytes();
+    }
+};
+
+namespace {
+
+int alloc_slots(arcte_hip_ctx *c, int64_t slots, uint32_t qcap)
+{
+    HIP_TRY(c->rs.alloc((size_t)slots * c->n));
+    HIP_TRY(c->sup.alloc((size_t)slots * c->n));
+    HIP_TRY(c->queue.alloc((size_t)slots * qcap));
+    HIP_TRY(hipMemsetAsync(c->rs.p, 0, c->rs.bytes(), c->stream));
+    c->slots = slots;
+    c->qcap = qcap;
+    return 0;
+}
+
+int grow_queue(arcte_hip_ctx *c)
+{
+    if (c->qcap >= (1u << 30)) return fail(ARCTE_HIP_ECAPACITY, "FIFO ring cannot grow past 2^30 entries");
+    uint32_t nq = c->qcap * 4;
+    // keep the footprint bounded: fewer, deeper slots once rings get large
+    int64_t slots = c->slots;
+    while (slots > WAVES_PER_BLOCK && (size_t)slots * nq * sizeof(int32_t) > ((size_t)8 << 30)) slots /= 2;
+    slots = std::max<int64_t>(WAVES_PER_BLOCK, slots - slots % WAVES_PER_BLOCK);
+    c->queue.release();
+    if (slots != c->slots) {
+        c->rs.release();
+        c->sup.release();
+        return alloc_slots(c, slots, nq);
+    }
+    HIP_TRY(c->queue.alloc((size_t)slots * nq));
+    c->qcap = nq;
+    return 0;
+}
+
+template <int MODE>
+int launch_seeds(arcte_hip_ctx *c, const PushParams &P, int64_t nwork)
+{
+    int64_t waves = std::min<int64_t>(c->slots, std::max<int64_t>(nwork, 1));
+    int blocks = (int)((waves + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
+    // MODE 1 works on the dense vectors the host placed in slot 0: exactly one wavefront may run
+    const int threads = (MODE == 1) ? WAVE : BLOCK;
+    if (MODE == 1) blocks = 1;
+    hipLaunchKernelGGL(k_arcte_seeds<MODE>, dim3(blocks), dim3(threads), 0, c->stream, P);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int arcte_hip_abi_version(void) { return 1; }
+
+const char *arcte_hip_last_error(void) { return g_err.c_str(); }
+
+int arcte_hip_device_count(int *count)
+{
+    if (!count) return fail(ARCTE_HIP_EINVAL, "count is NULL");
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        c = 0;
+    }
+    *count = c;
+    return 0;
+}
+
+int arcte_hip_create(int device, int64_t n, int64_t nnz, const int64_t *indptr, const int32_t *indices,
+                     const double *data, const double *out_degree, const double *in_degree, int64_t n_slots,
+                     int64_t queue_capacity, arcte_hip_ctx **out)
+{
+    if (!out) return fail(ARCTE_HIP_EINVAL, "out is NULL");
+    *out = nullptr;
+    if (n <= 0 || n >= (int64_t)1 << 31 || nnz < 0) return fail(ARCTE_HIP_EINVAL, "n must be in [1, 2^31), nnz >= 0");
+    if (!indptr || !out_degree || !in_degree || (nnz > 0 && (!indices || !data)))
+        return fail(ARCTE_HIP_EINVAL, "NULL graph array");
+    if (indptr[0] != 0 || indptr[n] != nnz) return fail(ARCTE_HIP_EINVAL, "indptr does not span [0, nnz]");
+    for (int64_t i = 0; i < n; i++)
+        if (indptr[i + 1] < indptr[i]) return fail(ARCTE_HIP_EINVAL, "indptr is not monotone");
+    for (int64_t k = 0; k < nnz; k++)
+        if (indices[k] < 0 || indices[k] >= n) return fail(ARCTE_HIP_EINVAL, "column index out of range");
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail(ARCTE_HIP_EHIP, "no such HIP device");
+    HIP_TRY(hipSetDevice(device));
+    arcte_hip_ctx *c = new arcte_hip_ctx();
+    c->device = device;
+    c->n = n;
+    c->nnz = nnz;
+    int rc = [&]() -> int {
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, device));
+        c->cus = prop.multiProcessorCount;
+        HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        for (auto &e : c->ev) HIP_TRY(hipEventCreate(&e));
+        HIP_TRY(c->indptr.alloc(n + 1));
+        HIP_TRY(c->indices.alloc(nnz));
+        HIP_TRY(c->data.alloc(nnz));
+        HIP_TRY(c->out_degree.alloc(n));
+        HIP_TRY(c->in_degree.alloc(n));
+        HIP_TRY(hipMemcpyAsync(c->indptr.p, indptr, (n + 1) * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
+        if (nnz) {
+            HIP_TRY(hipMemcpyAsync(c->indices.p, indices, nnz * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipMemcpyAsync(c->data.p, data, nnz * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        }
+        HIP_TRY(hipMemcpyAsync(c->out_degree.p, out_degree, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->in_degree.p, in_degree, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c->counters.alloc(8));
+        int64_t slots = n_slots;
+        if (slots <= 0) {
+            int per_cu = 0;
+            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_arcte_seeds<0>, BLOCK, 0));
+            per_cu = std::max(1, std::min(per_cu, 8));
+            slots = (int64_t)per_cu * c->cus * WAVES_PER_BLOCK;
+            // keep the slot scratch within a fixed share of the device
+            size_t free_b = 0, total_b = 0;
+            HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+            size_t per_slot = (size_t)n * (sizeof(double2) + sizeof(int32_t)) + (size_t)next_pow2(std::max<int64_t>(n, 4096)) * 4;
+            while (slots > WAVES_PER_BLOCK && (size_t)slots * per_slot > free_b / 2) slots /= 2;
+        }
+        slots = std::max<int64_t>(WAVES_PER_BLOCK, (slots + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK * WAVES_PER_BLOCK);
+        uint32_t qcap = next_pow2((uint64_t)(queue_capacity > 0 ? queue_capacity : std::max<int64_t>(n, 4096)));
+        if (qcap < (uint32_t)WAVE) qcap = WAVE;
+        int r = alloc_slots(c, slots, qcap);
+        if (r) return r;
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        return 0;
+    }();
+    if (rc) {
+        std::string keep = g_err;
+        arcte_hip_destroy(c);
+        g_err = keep;
+        return rc;
+    }
+    *out = c;
+    return 0;
+}
+
+int arcte_hip_destroy(arcte_hip_ctx *c)
+{
+    if (!c) return 0;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    c->indptr.release(); c->indices.release(); c->data.release(); c->out_degree.release(); c->in_degree.release();
+    c->rs.release(); c->queue.release(); c->sup.release();
+    c->seeds_d.release(); c->work_pos.release(); c->out_cnt.release(); c->status.release(); c->nop_d.release();
+    c->eps_d.release(); c->out_off.release(); c->dst_off.release(); c->counters.release();
+    c->raw.release(); c->rows_final.release();
+    for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return 0;
+}
+
+static int upload_seeds(arcte_hip_ctx *c, const int64_t *seeds, int64_t nseeds)
+{
+    std::vector<int32_t> s32((size_t)std::max<int64_t>(nseeds, 1));
+    for (int64_t k = 0; k < nseeds; k++) {
+        if (seeds[k] < 0 || seeds[k] >= c->n) return fail(ARCTE_HIP_EINVAL, "seed id out of range");
+        s32[k] = (int32_t)seeds[k];
+    }
+    HIP_TRY(c->seeds_d.alloc(nseeds));
+    HIP_TRY(c->eps_d.alloc(nseeds));
+    if (nseeds) HIP_TRY(hipMemcpy(c->seeds_d.p, s32.data(), nseeds * sizeof(int32_t), hipMemcpyHostToDevice));
+    return 0;
+}
+
+static int launch_eps(arcte_hip_ctx *c, int64_t nseeds, double epsilon)
+{
+    if (nseeds == 0) return 0;
+    int blocks = (int)((nseeds + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
+    hipLaunchKernelGGL(k_epsilon_effective, dim3(blocks), dim3(BLOCK), 0, c->stream, c->graph(), c->seeds_d.p, nseeds,
+                       epsilon, c->eps_d.p);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int arcte_hip_epsilon_effective(arcte_hip_ctx *c, const int64_t *seeds, int64_t nseeds, double epsilon, double *eps_out)
+{
+    if (!c || nseeds < 0 || (nseeds && (!seeds || !eps_out))) return fail(ARCTE_HIP_EINVAL, "bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    c->run_nseeds = -1;
+    int r = upload_seeds(c, seeds, nseeds);
+    if (r) return r;
+    r = launch_eps(c, nseeds, epsilon);
+    if (r) return r;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (nseeds) HIP_TRY(hipMemcpy(eps_out, c->eps_d.p, nseeds * sizeof(double), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int arcte_hip_run_seeds(arcte_hip_ctx *c, const int64_t *seeds, int64_t nseeds, double rho, double epsilon,
+                        int use_effective_epsilon)
+{
+    if (!c || nseeds < 0 || (nseeds && !seeds)) return fail(ARCTE_HIP_EINVAL, "bad argument");
+    if (nseeds >= ((int64_t)1 << 31)) return fail(ARCTE_HIP_EINVAL, "too many seeds for one call");
+    HIP_TRY(hipSetDevice(c->device));
+    auto t0 = std::chrono::steady_clock::now();
+    c->run_nseeds = -1;
+    c->final_rows = 0;
+    for (auto &s : c->stats) s = 0;
+    for (auto &m : c->ms) m = 0;
+    int r = upload_seeds(c, seeds, nseeds);
+    if (r) return r;
+    HIP_TRY(c->out_cnt.alloc(nseeds));
+    HIP_TRY(c->status.alloc(nseeds));
+    HIP_TRY(c->nop_d.alloc(nseeds));
+    HIP_TRY(c->out_off.alloc(nseeds));
+    HIP_TRY(c->dst_off.alloc(nseeds));
+    HIP_TRY(c->work_pos.alloc(nseeds));
+    c->colptr.assign((size_t)nseeds + 1, 0);
+    if (nseeds == 0) {
+        c->run_nseeds = 0;
+        return 0;
+    }
+
+    // a4
+    HIP_TRY(hipEventRecord(c->ev[0], c->stream));
+    if (use_effective_epsilon) {
+        r = launch_eps(c, nseeds, epsilon);
+        if (r) return r;
+    } else {
+        std::vector<double> e((size_t)nseeds, epsilon);
+        HIP_TRY(hipMemcpyAsync(c->eps_d.p, e.data(), nseeds * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    HIP_TRY(hipEventRecord(c->ev[1], c->stream));
+
+    // raw arena: grows on demand (seeds that did not fit are re-run)
+    if (c->raw.count == 0) {
+        size_t free_b = 0, total_b = 0;
+        HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+        size_t want = std::max<size_t>((size_t)c->n, std::min<size_t>((size_t)nseeds * 1024, (size_t)1 << 30));
+        want = std::min(want, std::max<size_t>((size_t)c->n, free_b / 16));
+        if (const char *env = getenv("ARCTE_HIP_ARENA_ROWS")) {   // test hook: force a small arena
+            long long v = atoll(env);
+            if (v > 0) want = std::max<size_t>((size_t)c->n, (size_t)v);
+        }
+        HIP_TRY(c->raw.alloc(want));
+    }
+
+    std::vector<int32_t> work((size_t)nseeds), next;   // positions (into seeds[]) still to run
+    for (int64_t k = 0; k < nseeds; k++) work[k] = (int32_t)k;
+    std::vector<int32_t> status_h((size_t)nseeds), cnt_h((size_t)nseeds);
+    std::vector<int64_t> dst_h((size_t)nseeds, 0);
+    std::vector<int64_t> seg_start((size_t)nseeds, 0);   // where each seed's rows sit in rows_final (launch order)
+    bool identity = true;
+    int64_t final_used = 0;
+    double ms_push = 0, ms_compact = 0;
+    int launches = 0;
+    while (!work.empty()) {
+        const int64_t nwork = (int64_t)work.size();
+        if (!identity)
+            HIP_TRY(hipMemcpyAsync(c->work_pos.p, work.data(), nwork * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemsetAsync(c->counters.p, 0, 8 * sizeof(unsigned long long), c->stream));
+        PushParams P;
+        P.g = c->graph();
+        P.work_pos = identity ? nullptr : c->work_pos.p;
+        P.nwork = nwork;
+        P.work_counter = c->counters.p + 0;
+        P.seeds = c->seeds_d.p;
+        P.eps = c->eps_d.p;
+        P.one_minus_rho = 1 - rho;
+        P.rs = c->rs.p;
+        P.queue = c->queue.p;
+        P.sup = c->sup.p;
+        P.qcap = c->qcap;
+        P.max_pushes = max_pushes_limit();
+        P.raw = c->raw.p;
+        P.rawcap = c->raw.count;
+        P.raw_cursor = c->counters.p + 1;
+        P.out_off = c->out_off.p;
+        P.out_cnt = c->out_cnt.p;
+        P.status = c->status.p;
+        P.nop = c->nop_d.p;
+        P.stats = c->counters.p + 2;
+        HIP_TRY(hipEventRecord(c->ev[2], c->stream));
+        r = launch_seeds<0>(c, P, nwork);
+        if (r) return r;
+        HIP_TRY(hipEventRecord(c->ev[3], c->stream));
+        launches++;
+        unsigned long long cnt8[8];
+        HIP_TRY(hipMemcpyAsync(cnt8, c->counters.p, sizeof(cnt8), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(status_h.data(), c->status.p, nseeds * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(cnt_h.data(), c->out_cnt.p, nseeds * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, c->ev[2], c->ev[3]));
+        ms_push += ms;
+        for (int i = 0; i < 4; i++) c->stats[i] += (int64_t)cnt8[2 + i];
+
+        // finished seeds of this launch: their rows are appended to rows_final in work-list order
+        next.clear();
+        bool queue_over = false, out_over = false;
+        int64_t add = 0;
+        for (int32_t pos : work) {
+            const int32_t st = status_h[pos];
+            dst_h[pos] = final_used + add;
+            if (st == ST_OK) {
+                seg_start[pos] = dst_h[pos];
+                c->colptr[(size_t)pos + 1] = cnt_h[pos];
+                add += cnt_h[pos];
+            } else if (st == ST_RUNAWAY) {
+                return fail(ARCTE_HIP_ECAPACITY, "seed " + std::to_string(seeds[pos]) + ": push cap reached (" +
+                                                     std::to_string(max_pushes_limit()) + " pushes without converging)");
+            } else if (st == ST_MISSING_BASE) {
+                return fail(ARCTE_HIP_EGRAPH, "seed " + std::to_string(seeds[pos]) +
+                                                  ": closed neighbourhood not contained in the support (zero-weight edge?)");
+            } else {
+                queue_over |= (st == ST_QUEUE_OVERFLOW);
+                out_over |= (st == ST_OUTPUT_OVERFLOW);
+                next.push_back(pos);
+            }
+        }
+        if (add > 0) {
+            if ((size_t)(final_used + add) > c->rows_final.count) {
+                DevBuf<int32_t> bigger;
+                size_t want = std::max<size_t>((size_t)(final_used + add), c->rows_final.count * 2);
+                HIP_TRY(bigger.alloc(want));
+                if (final_used)
+                    HIP_TRY(hipMemcpyAsync(bigger.p, c->rows_final.p, final_used * sizeof(int32_t), hipMemcpyDeviceToDevice, c->stream));
+                HIP_TRY(hipStreamSynchronize(c->stream));
+                c->rows_final.release();
+                c->rows_final = bigger;
+                bigger.p = nullptr;
+            }
+            HIP_TRY(hipMemcpyAsync(c->dst_off.p, dst_h.data(), nseeds * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipEventRecord(c->ev[4], c->stream));
+            int blocks = (int)((nwork + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
+            // failed seeds wrote a zero count, so they copy nothing
+            hipLaunchKernelGGL(k_gather_segments, dim3(blocks), dim3(BLOCK), 0, c->stream, c->raw.p, c->out_off.p,
+                               c->out_cnt.p, c->dst_off.p, c->rows_final.p, P.work_pos, nwork);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipEventRecord(c->ev[5], c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            HIP_TRY(hipEventElapsedTime(&ms, c->ev[4], c->ev[5]));
+            ms_compact += ms;
+            final_used += add;
+        }
+        if (!next.empty()) {
+            c->stats[4] += (int64_t)next.size();
+            if (queue_over) {
+                r = grow_queue(c);
+                if (r) return r;
+            }
+            if (out_over && next.size() == (size_t)nwork) {
+                // not a single seed fitted: the arena itself is too small
+                if (c->raw.count >= ((size_t)1 << 33)) return fail(ARCTE_HIP_ECAPACITY, "no seed fits the output arena");
+                size_t want = c->raw.count * 4;
+                HIP_TRY(c->raw.alloc(want));
+            }
+        }
+        work.swap(next);
+        identity = false;
+    }
+    c->stats[5] = launches;
+
+    // colptr in seed order; rows_final is in launch order -> one more gather when there were re-runs
+    for (int64_t k = 0; k < nseeds; k++) c->colptr[k + 1] += c->colptr[k];
+    if (launches > 1 && final_used > 0) {
+        DevBuf<int32_t> ordered;
+        HIP_TRY(ordered.alloc(final_used));
+        std::vector<int32_t> cnt_all((size_t)nseeds);
+        for (int64_t k = 0; k < nseeds; k++) cnt_all[k] = (int32_t)(c->colptr[k + 1] - c->colptr[k]);
+        HIP_TRY(hipMemcpyAsync(c->out_cnt.p, cnt_all.data(), nseeds * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->out_off.p, seg_start.data(), nseeds * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->dst_off.p, c->colptr.data(), nseeds * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
+        int blocks = (int)((nseeds + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
+        hipLaunchKernelGGL(k_gather_segments, dim3(blocks), dim3(BLOCK), 0, c->stream, c->rows_final.p, c->out_off.p,
+                           c->out_cnt.p, c->dst_off.p, ordered.p, (const int32_t *)nullptr, nseeds);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        c->rows_final.release();
+        c->rows_final = ordered;
+        ordered.p = nullptr;
+    }
+    c->final_rows = final_used;
+    c->run_nseeds = nseeds;
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+    c->ms[0] = ms;
+    c->ms[1] = ms_push;
+    c->ms[2] = ms_compact;
+    c->ms[3] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return 0;
+}
+
+int arcte_hip_result_sizes(arcte_hip_ctx *c, int64_t *nseeds, int64_t *total_rows)
+{
+    if (!c) return fail(ARCTE_HIP_EINVAL, "ctx is NULL");
+    if (c->run_nseeds < 0) return fail(ARCTE_HIP_ESTATE, "no completed run on this context");
+    if (nseeds) *nseeds = c->run_nseeds;
+    if (total_rows) *total_rows = c->final_rows;
+    return 0;
+}
+
+int arcte_hip_fetch_result(arcte_hip_ctx *c, int64_t *colptr, int32_t *rows, double *eps_used, int64_t *nop)
+{
+    if (!c) return fail(ARCTE_HIP_EINVAL, "ctx is NULL");
+    if (c->run_nseeds < 0) return fail(ARCTE_HIP_ESTATE, "no completed run on this context");
+    HIP_TRY(hipSetDevice(c->device));
+    const int64_t ns = c->run_nseeds;
+    if (colptr) memcpy(colptr, c->colptr.data(), (ns + 1) * sizeof(int64_t));
+    if (rows && c->final_rows)
+        HIP_TRY(hipMemcpy(rows, c->rows_final.p, c->final_rows * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (eps_used && ns) HIP_TRY(hipMemcpy(eps_used, c->eps_d.p, ns * sizeof(double), hipMemcpyDeviceToHost));
+    if (nop && ns) {
+        std::vector<int32_t> tmp((size_t)ns);
+        HIP_TRY(hipMemcpy(tmp.data(), c->nop_d.p, ns * sizeof(int32_t), hipMemcpyDeviceToHost));
+        for (int64_t k = 0; k < ns; k++) nop[k] = tmp[k];
+    }
+    return 0;
+}
+
+int arcte_hip_result_device_rows(arcte_hip_ctx *c, void **rows_dev)
+{
+    if (!c || !rows_dev) return fail(ARCTE_HIP_EINVAL, "bad argument");
+    if (c->run_nseeds < 0) return fail(ARCTE_HIP_ESTATE, "no completed run on this context");
+    *rows_dev = c->rows_final.p;
+    return 0;
+}
+
+int arcte_hip_run_stats(arcte_hip_ctx *c, int64_t stats[6])
+{
+    if (!c || !stats) return fail(ARCTE_HIP_EINVAL, "bad argument");
+    if (c->run_nseeds < 0) return fail(ARCTE_HIP_ESTATE, "no completed run on this context");
+    for (int i = 0; i < 6; i++) stats[i] = c->stats[i];
+    return 0;
+}
+
+int arcte_hip_run_timing(arcte_hip_ctx *c, double ms[4])
+{
+    if (!c || !ms) return fail(ARCTE_HIP_EINVAL, "bad argument");
+    if (c->run_nseeds < 0) return fail(ARCTE_HIP_ESTATE, "no completed run on this context");
+    for (int i = 0; i < 4; i++) ms[i] = c->ms[i];
+    return 0;
+}
+
+int arcte_hip_similarity_slice(arcte_hip_ctx *c, int64_t seed, double rho, double epsilon, double *s, double *r,
+                               int64_t *nop)
+{
+    if (!c || !s || !r) return fail(ARCTE_HIP_EINVAL, "bad argument");
+    if (seed < 0 || seed >= c->n) return fail(ARCTE_HIP_EINVAL, "seed id out of range");
+    HIP_TRY(hipSetDevice(c->device));
+    c->run_nseeds = -1;
+    const int64_t n = c->n;
+    DevBuf<double> sd, rd;
+    DevBuf<int32_t> seed_d, small;     // small: cnt, status, nop
+    DevBuf<int64_t> off_d;
+    DevBuf<double> eps1;
+    int rc = [&]() -> int {
+        HIP_TRY(sd.alloc(n));
+        HIP_TRY(rd.alloc(n));
+        HIP_TRY(seed_d.alloc(1));
+        HIP_TRY(small.alloc(3));
+        HIP_TRY(off_d.alloc(1));
+        HIP_TRY(eps1.alloc(1));
+        int32_t s32 = (int32_t)seed;
+        HIP_TRY(hipMemcpy(seed_d.p, &s32, sizeof(s32), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(eps1.p, &epsilon, sizeof(double), hipMemcpyHostToDevice));
+        for (;;) {
+            HIP_TRY(hipMemcpyAsync(sd.p, s, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipMemcpyAsync(rd.p, r, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+            const int tb = 256;
+            hipLaunchKernelGGL(k_interleave, dim3((unsigned)((n + tb - 1) / tb)), dim3(tb), 0, c->stream, sd.p, rd.p, c->rs.p, n);
+            HIP_TRY(hipMemsetAsync(c->counters.p, 0, 8 * sizeof(unsigned long long), c->stream));
+            PushParams P;
+            P.g = c->graph();
+            P.work_pos = nullptr;
+            P.nwork = 1;
+            P.work_counter = c->counters.p + 0;
+            P.seeds = seed_d.p;
+            P.eps = eps1.p;
+            P.one_minus_rho = 1 - rho;
+            P.rs = c->rs.p;
+            P.queue = c->queue.p;
+            P.sup = c->sup.p;
+            P.qcap = c->qcap;
+            P.max_pushes = max_pushes_limit();
+            P.raw = nullptr;
+            P.rawcap = 0;
+            P.raw_cursor = c->counters.p + 1;
+            P.out_off = off_d.p;
+            P.out_cnt = small.p + 0;
+            P.status = small.p + 1;
+            P.nop = small.p + 2;
+            P.stats = c->counters.p + 2;
+            int r2 = launch_seeds<1>(c, P, 1);
+            if (r2) return r2;
+            int32_t h[3];
+            HIP_TRY(hipMemcpyAsync(h, small.p, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            if (h[1] == ST_RUNAWAY) {
+                HIP_TRY(hipMemsetAsync(c->rs.p, 0, n * sizeof(double2), c->stream));
+                HIP_TRY(hipStreamSynchronize(c->stream));
+                return fail(ARCTE_HIP_ECAPACITY, "push cap reached after " + std::to_string(h[2]) + " pushes");
+            }
+            if (h[1] == ST_QUEUE_OVERFLOW) {
+                // slot 0 must be clean again for later runs; then retry with a deeper ring
+                HIP_TRY(hipMemsetAsync(c->rs.p, 0, n * sizeof(double2), c->stream));
+                r2 = grow_queue(c);
+                if (r2) return r2;
+                continue;
+            }
+            hipLaunchKernelGGL(k_deinterleave, dim3((unsigned)((n + tb - 1) / tb)), dim3(tb), 0, c->stream, c->rs.p, sd.p, rd.p, n);
+            HIP_TRY(hipMemcpyAsync(s, sd.p, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipMemcpyAsync(r, rd.p, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipMemsetAsync(c->rs.p, 0, n * sizeof(double2), c->stream));   // slot 0 back to all-zero
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            if (nop) *nop = h[2];
+            return 0;
+        }
+    }();
+    sd.release(); rd.release(); seed_d.release(); small.release(); off_d.release(); eps1.release();
+    return rc;
+}
+
+int arcte_hip_push(int device, int64_t n, double *s, double *r, const double *w_i, const int32_t *a_i, int64_t deg,
+                   int64_t push_node, double rho)
+{
+    if (!s || !r || n <= 0 || deg < 0 || (deg && (!w_i || !a_i))) return fail(ARCTE_HIP_EINVAL, "bad argument");
+    if (push_node < 0 || push_node >= n) return fail(ARCTE_HIP_EINVAL, "push_node out of range");
+    for (int64_t k = 0; k < deg; k++)
+        if (a_i[k] < 0 || a_i[k] >= n) return fail(ARCTE_HIP_EINVAL, "adjacent node out of range");
+    HIP_TRY(hipSetDevice(device));
+    DevBuf<double> sd, rd, wd;
+    DevBuf<int32_t> ad;
+    int rc = [&]() -> int {
+        HIP_TRY(sd.alloc(n));
+        HIP_TRY(rd.alloc(n));
+        HIP_TRY(wd.alloc(deg));
+        HIP_TRY(ad.alloc(deg));
+        HIP_TRY(hipMemcpy(sd.p, s, n * sizeof(double), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(rd.p, r, n * sizeof(double), hipMemcpyHostToDevice));
+        if (deg) {
+            HIP_TRY(hipMemcpy(wd.p, w_i, deg * sizeof(double), hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(ad.p, a_i, deg * sizeof(int32_t), hipMemcpyHostToDevice));
+        }
+        hipLaunchKernelGGL(k_single_push, dim3(1), dim3(BLOCK), 0, 0, sd.p, rd.p, wd.p, ad.p, deg, push_node, 1 - rho);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemcpy(s, sd.p, n * sizeof(double), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(r, rd.p, n * sizeof(double), hipMemcpyDeviceToHost));
+        return 0;
+    }();
+    sd.release(); rd.release(); wd.release(); ad.release();
+    return rc;
+}
+
+int arcte_hip_info(arcte_hip_ctx *c, int64_t info[5])
+{
+    if (!c || !info) return fail(ARCTE_HIP_EINVAL, "bad argument");
+    info[0] = c->slots;
+    info[1] = c->qcap;
+    info[2] = (int64_t)c->device_bytes();
+    info[3] = c->cus;
+    info[4] = WAVES_PER_BLOCK;
+    return 0;
+}
+
+}  // extern "C"

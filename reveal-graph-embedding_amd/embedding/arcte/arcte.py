@@ -1,0 +1,140 @@
+"""Mirror of reveal_graph_embedding/embedding/arcte/arcte.py for the ARCTE driver
+(reference lines 14-50, 279-388, 591-688).  The propagation, the effective-epsilon rule and the
+community extraction all run in HIP kernels behind reveal_graph_embedding_amd._native."""
+import itertools
+import threading
+
+import numpy as np
+import scipy.sparse as sparse
+
+from reveal_graph_embedding_amd import _native
+from reveal_graph_embedding_amd.eps_randomwalk.transition import get_natural_random_walk_matrix
+
+
+def parallel_chunks(l, n):
+    for thread_id in range(n):
+        yield roundrobin_chunks(l, n, thread_id)
+
+
+def roundrobin_chunks(l, n, id):
+    l_c = iter(l)
+    x = list(itertools.islice(l_c, id, None, n))
+    if len(x):
+        return x
+
+
+def calculate_epsilon_effective(rho, epsilon, seed_degree, neighbor_degrees, mean_degree):
+    """
+    Semi-automatic effective epsilon threshold calculation (reference arcte.py:26-50).
+
+    Evaluated by the same kernel arcte_worker uses, on a star graph whose hub carries `seed_degree`
+    and whose leaves carry `neighbor_degrees`.  rho and mean_degree are unused, as in the reference.
+    """
+    nd = np.ascontiguousarray(neighbor_degrees, dtype=np.float64).reshape(-1)
+    m = nd.size
+    if m == 0:
+        raise ValueError("zero-size array to reduction operation maximum which has no identity")
+    indptr = np.zeros(m + 2, dtype=np.int64)
+    indptr[1:] = m
+    indices = np.arange(1, m + 1, dtype=np.int32)
+    out_degree = np.concatenate([[float(seed_degree)], nd])
+    with _native.Context(indptr, indices, np.ones(m), out_degree, np.ones(m + 1), n_slots=4) as ctx:
+        return float(ctx.epsilon_effective(np.zeros(1, dtype=np.int64), epsilon)[0])
+
+
+def _seed_matrix(n, seeds, colptr, rows):
+    cols = np.repeat(np.asarray(seeds, dtype=np.int64), np.diff(colptr))
+    features = sparse.coo_matrix((np.ones(rows.size, dtype=np.float64), (rows.astype(np.int64), cols)), shape=(n, n))
+    return sparse.csr_matrix(features)
+
+
+def arcte_worker(iterate_nodes, indices_c, indptr_c, data_c, out_degree, in_degree, rho, epsilon, device=0):
+    """
+    Local community features of the seeds in `iterate_nodes` (reference arcte.py:279-388): n x n CSR of
+    ones whose column j holds the local community of seed j.  Takes the flat CSR arrays of the
+    random-walk matrix exactly as the reference's pool workers do; `device` picks the GPU.
+    """
+    iterate_nodes = np.asarray(iterate_nodes, dtype=np.int64).reshape(-1)
+    number_of_nodes = out_degree.size
+    with _native.Context(indptr_c, indices_c, data_c, out_degree, in_degree, device=device) as ctx:
+        ctx.run_seeds(iterate_nodes, rho, epsilon, use_effective_epsilon=True)
+        colptr, rows = ctx.fetch()
+    return _seed_matrix(number_of_nodes, iterate_nodes, colptr, rows)
+
+
+def seed_nodes(adjacency_matrix):
+    """Seed list of the reference (arcte.py:610-617): nodes whose pattern in-count exceeds 1, by
+    descending count.  Ties are ordered by node id here (the reference's unstable argsort leaves
+    them unspecified; the order only decides which worker handles a seed)."""
+    a = sparse.csr_matrix(adjacency_matrix)
+    edge_count_vector = np.bincount(a.indices, minlength=a.shape[1]).astype(np.int64)
+    iterate_nodes = np.where(edge_count_vector > 1)[0]
+    order = np.argsort(-edge_count_vector[iterate_nodes], kind="stable")
+    return iterate_nodes[order]
+
+
+def arcte(adjacency_matrix, rho, epsilon, number_of_threads=None):
+    """
+    Extracts local community features for all graph nodes based on the partitioning of node-centric
+    similarity vectors (reference arcte.py:591-688).
+
+    Inputs:  - A in R^(nxn): adjacency matrix (any scipy sparse format).
+             - rho: restart probability.
+             - epsilon: approximation threshold.
+             - number_of_threads: the reference's process count.  Here it bounds the number of GPUs
+               used (None = every visible GPU); seeds are dealt round-robin over them exactly like
+               the reference deals them over its processes (arcte.py:14-23, 650-651).
+
+    Outputs: - X in R^(nx2n): CSR; columns [0, n) are the base communities I + pattern(A),
+               columns [n, 2n) the ARCTE local communities.
+    """
+    adjacency_matrix = sparse.csr_matrix(adjacency_matrix)
+    number_of_nodes = adjacency_matrix.shape[0]
+
+    n_gpus = _native.device_count()
+    if n_gpus < 1:
+        raise _native.ArcteHipError(-2, "no HIP device visible (there is no CPU fallback)")
+    if number_of_threads is not None:
+        n_gpus = max(1, min(n_gpus, int(number_of_threads)))
+
+    rw_transition, out_degree, in_degree = get_natural_random_walk_matrix(adjacency_matrix)
+    iterate_nodes = seed_nodes(adjacency_matrix)
+
+    if n_gpus == 1 or iterate_nodes.size < 2:
+        local_features = arcte_worker(iterate_nodes, rw_transition.indices, rw_transition.indptr, rw_transition.data,
+                                      out_degree, in_degree, rho, epsilon)
+    else:
+        chunks = [c for c in parallel_chunks(iterate_nodes, n_gpus)]
+        results = [None] * n_gpus
+        errors = []
+
+        def work(k):
+            try:
+                if chunks[k] is not None:
+                    results[k] = arcte_worker(chunks[k], rw_transition.indices, rw_transition.indptr,
+                                              rw_transition.data, out_degree, in_degree, rho, epsilon, device=k)
+            except BaseException as e:  # surfaced below; the reference drops worker errors silently
+                errors.append(e)
+
+        threads = [threading.Thread(target=work, args=(k,)) for k in range(n_gpus)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        if errors:
+            raise errors[0]
+        results = [x for x in results if x is not None]
+        local_features = results[0]
+        for additive_features in results[1:]:
+            local_features = local_features + additive_features
+        local_features = sparse.csr_matrix(local_features)
+
+    # Form base community feature matrix (arcte.py:676-679).
+    identity_matrix = sparse.csr_matrix(sparse.eye(number_of_nodes, number_of_nodes, dtype=np.float64))
+    adjacency_matrix_ones = adjacency_matrix.copy()
+    adjacency_matrix_ones.data = np.ones_like(adjacency_matrix_ones.data, dtype=np.float64)
+    base_community_features = identity_matrix + adjacency_matrix_ones
+
+    # Stack horizontally matrices to form feature matrix (arcte.py:683).
+    features = sparse.hstack([base_community_features, local_features]).tocsr()
+    return features

@@ -1,0 +1,236 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle and the reference's fixtures.
+
+Bit-exact bar: sparsity patterns, push counts, and -- because the kernels keep the reference's
+operation order with FMA contraction off -- the float64 values of s and r as well.  The one
+tolerance is the effective epsilon, whose two logarithms come from the device libm (rtol below).
+"""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sparse
+
+from conftest import GOLDEN, assert_same_sparse, load_golden
+from oracle import oracle
+
+from reveal_graph_embedding_amd import _native
+from reveal_graph_embedding_amd.embedding.arcte.arcte import arcte, arcte_worker, calculate_epsilon_effective
+from reveal_graph_embedding_amd.eps_randomwalk.push import cumulative_pagerank_difference_limit_push
+from reveal_graph_embedding_amd.eps_randomwalk.similarity import (
+    fast_approximate_cumulative_pagerank_difference, similarity_slice_cython)
+from reveal_graph_embedding_amd.eps_randomwalk.transition import get_natural_random_walk_matrix
+from reveal_graph_embedding_amd.synthetic import rmat_graph
+
+pytestmark = pytest.mark.gpu
+
+EPS_RTOL = 4e-15   # a few ulp: eps*log(1+d)/log(1+mean) with device log (<= 1 ulp each)
+
+
+def ctx_of(g, **kw):
+    w = g["w"]
+    return _native.Context(w.indptr, w.indices, w.data, g["out_degree"], g["in_degree"], **kw)
+
+
+def arrays_of_arrays(w):
+    n = w.shape[0]
+    a_i = np.ndarray(n, dtype=np.ndarray)
+    w_i = np.ndarray(n, dtype=np.ndarray)
+    for i in range(n):
+        a_i[i] = w.indices[w.indptr[i]:w.indptr[i + 1]]
+        w_i[i] = w.data[w.indptr[i]:w.indptr[i + 1]]
+    return w_i, a_i
+
+
+def test_device_visible():
+    assert _native.device_count() >= 1
+
+
+def test_epsilon_effective_all_seeds(golden):
+    with ctx_of(golden) as ctx:
+        got = ctx.epsilon_effective(golden["all_seeds"], golden["epsilon"])
+    want = golden["all_eps_eff"]
+    np.testing.assert_allclose(got, want, rtol=EPS_RTOL, atol=0)
+    print("eps_eff bit-identical: %d / %d" % (int((got == want).sum()), want.size))
+
+
+def test_epsilon_effective_scalar_api(golden):
+    w, od = golden["w"], golden["out_degree"]
+    for k, s in enumerate(golden["seeds"][:4]):
+        e = calculate_epsilon_effective(golden["rho"], golden["epsilon"], od[s],
+                                        od[w.indices[w.indptr[s]:w.indptr[s + 1]]], od.mean())
+        np.testing.assert_allclose(e, golden["eps_eff"][k], rtol=EPS_RTOL, atol=0)
+
+
+def test_single_push_bit_exact(golden):
+    w = golden["w"]
+    u = int(golden["push_node"])
+    s, r = golden["push_s_in"].copy(), golden["push_r_in"].copy()
+    cumulative_pagerank_difference_limit_push(s, r, w.data[w.indptr[u]:w.indptr[u + 1]],
+                                              w.indices[w.indptr[u]:w.indptr[u + 1]], u, golden["rho"])
+    assert np.array_equal(s, golden["push_s_out"])
+    assert np.array_equal(r, golden["push_r_out"])
+
+
+@pytest.mark.parametrize("flavour", ["", "raw_"])
+def test_similarity_slices_bit_exact(golden, flavour):
+    """fast_approximate_cumulative_pagerank_difference with the reference's own call shape."""
+    n = golden["n"]
+    w_i, a_i = arrays_of_arrays(golden["w"])
+    assert similarity_slice_cython is fast_approximate_cumulative_pagerank_difference
+    for k, seed in enumerate(golden["seeds"]):
+        eps = golden["eps_eff"][k] if flavour == "" else golden["epsilon"]
+        s = np.zeros(n)
+        r = np.zeros(n)
+        nop = fast_approximate_cumulative_pagerank_difference(s, r, w_i, a_i, golden["out_degree"],
+                                                              golden["in_degree"], seed, golden["rho"], eps)
+        assert nop == golden[flavour + "nop"][k]
+        for vec, tag in ((s, "s"), (r, "r")):
+            lo, hi = golden[flavour + tag + "_ptr"][k], golden[flavour + tag + "_ptr"][k + 1]
+            nz = np.nonzero(vec)[0]
+            assert np.array_equal(nz, golden[flavour + tag + "_idx"][lo:hi])
+            assert np.array_equal(vec[nz], golden[flavour + tag + "_val"][lo:hi])
+
+
+def test_similarity_slice_continues_from_caller_state(golden):
+    """s and r are the caller's: a non-zero start state must be carried like the reference does."""
+    n = golden["n"]
+    rng = np.random.default_rng(5)
+    s0 = rng.random(n) * 1e-3
+    r0 = rng.random(n) * 1e-4
+    seed = int(golden["seeds"][0])
+    s_o, r_o = s0.copy(), r0.copy()
+    nop_o = oracle.similarity(golden["w"], golden["in_degree"], seed, golden["rho"], 1e-3, s_o, r_o)
+    with ctx_of(golden, n_slots=4) as ctx:
+        s_h, r_h = s0.copy(), r0.copy()
+        nop_h = ctx.similarity_slice(seed, golden["rho"], 1e-3, s_h, r_h)
+    assert nop_h == nop_o
+    assert np.array_equal(s_h, s_o) and np.array_equal(r_h, r_o)
+
+
+def test_worker_matches_fixture_and_oracle(golden):
+    w = golden["w"]
+    got = arcte_worker(golden["seeds"], w.indices, w.indptr, w.data, golden["out_degree"], golden["in_degree"],
+                       golden["rho"], golden["epsilon"])
+    assert_same_sparse(got, golden["worker"])
+    with ctx_of(golden) as ctx:
+        ctx.run_seeds(golden["seeds"], golden["rho"], golden["epsilon"])
+        colptr, rows, eps, nop = ctx.fetch(want_eps=True, want_nop=True)
+        st = ctx.stats()
+    assert np.array_equal(nop, golden["nop"])
+    np.testing.assert_allclose(eps, golden["eps_eff"], rtol=EPS_RTOL, atol=0)
+    o_colptr, o_rows, _, _, o_stats = oracle.worker(w, golden["out_degree"], golden["in_degree"], golden["seeds"],
+                                                    golden["rho"], golden["epsilon"], want_stats=True)
+    assert np.array_equal(colptr, o_colptr)
+    for k in range(golden["seeds"].size):
+        assert np.array_equal(np.sort(rows[colptr[k]:colptr[k + 1]]), o_rows[o_colptr[k]:o_colptr[k + 1]])
+    assert [st["pushes"], st["edges"], st["enqueues"], st["support"]] == list(o_stats)
+
+
+def test_arcte_full_matches_reference_fixture(golden):
+    got = arcte(golden["adjacency"], golden["rho"], golden["epsilon"], 1)
+    assert got.shape == (golden["n"], 2 * golden["n"])
+    assert_same_sparse(got, golden["feat1"])
+    assert_same_sparse(got, golden["feat3"])
+
+
+def test_raw_epsilon_mode_against_oracle():
+    g = load_golden("ba1500")
+    seeds = g["all_seeds"][::7]
+    with ctx_of(g) as ctx:
+        ctx.run_seeds(seeds, 0.15, 3e-5, use_effective_epsilon=False)
+        colptr, rows, eps, nop = ctx.fetch(want_eps=True, want_nop=True)
+    assert np.all(eps == 3e-5)
+    n = g["n"]
+    for k, seed in enumerate(seeds[:40]):
+        s, r = np.zeros(n), np.zeros(n)
+        assert oracle.similarity(g["w"], g["in_degree"], seed, 0.15, 3e-5, s, r) == nop[k]
+
+
+@pytest.mark.parametrize("qcap", [64, 256])
+def test_queue_overflow_is_detected_and_recovered(qcap):
+    g = load_golden("rmat2000")
+    seeds = g["all_seeds"]
+    with ctx_of(g, n_slots=64, queue_capacity=qcap) as ctx:
+        assert ctx.info()["queue_capacity"] == qcap
+        ctx.run_seeds(seeds, g["rho"], g["epsilon"])
+        colptr, rows = ctx.fetch()
+        st = ctx.stats()
+        assert ctx.info()["queue_capacity"] > qcap
+    assert st["reruns"] > 0 and st["launches"] > 1
+    o_colptr, o_rows = oracle.worker(g["w"], g["out_degree"], g["in_degree"], seeds, g["rho"], g["epsilon"])
+    assert np.array_equal(colptr, o_colptr)
+    for k in range(seeds.size):
+        assert np.array_equal(np.sort(rows[colptr[k]:colptr[k + 1]]), o_rows[o_colptr[k]:o_colptr[k + 1]])
+
+
+def test_output_arena_overflow_is_detected_and_recovered(monkeypatch):
+    g = load_golden("rmat2000")
+    seeds = g["all_seeds"]
+    monkeypatch.setenv("ARCTE_HIP_ARENA_ROWS", "20000")
+    with ctx_of(g, n_slots=64) as ctx:
+        ctx.run_seeds(seeds, g["rho"], g["epsilon"])
+        colptr, rows = ctx.fetch()
+        st = ctx.stats()
+    assert st["launches"] > 1
+    o_colptr, o_rows = oracle.worker(g["w"], g["out_degree"], g["in_degree"], seeds, g["rho"], g["epsilon"])
+    assert np.array_equal(colptr, o_colptr)
+    for k in range(seeds.size):
+        assert np.array_equal(np.sort(rows[colptr[k]:colptr[k + 1]]), o_rows[o_colptr[k]:o_colptr[k + 1]])
+
+
+def test_empty_seed_list_and_reuse_of_context():
+    g = load_golden("ba300")
+    with ctx_of(g) as ctx:
+        ctx.run_seeds(np.zeros(0, dtype=np.int64), 0.1, 1e-5)
+        colptr, rows = ctx.fetch()
+        assert colptr.tolist() == [0] and rows.size == 0
+        for _ in range(2):     # slots must come back all-zero after every run
+            ctx.run_seeds(g["seeds"], g["rho"], g["epsilon"])
+            colptr, rows, nop = ctx.fetch(want_nop=True)
+            assert np.array_equal(nop, g["nop"])
+
+
+def test_c_abi_error_codes():
+    g = load_golden("ba300")
+    with ctx_of(g) as ctx:
+        with pytest.raises(_native.ArcteHipError) as e:
+            ctx.fetch()
+        assert e.value.code == -4
+        with pytest.raises(_native.ArcteHipError) as e:
+            ctx.run_seeds(np.array([10 ** 9]), 0.1, 1e-5)
+        assert e.value.code == -1
+    with pytest.raises(_native.ArcteHipError) as e:
+        _native.Context(g["w"].indptr, g["w"].indices, g["w"].data, g["out_degree"], g["in_degree"], device=99)
+    assert e.value.code == -2
+
+
+def test_zero_weight_edge_is_reported_not_miscomputed():
+    """Star whose hub->leaf-1 transition weight is an explicit zero: leaf 1 can never receive mass, so
+    the hub's closed neighbourhood is not inside its support and the reference mis-indexes (arcte.py:359)."""
+    a = sparse.csr_matrix(np.array([[0, 1, 1, 1], [1, 0, 0, 0], [1, 0, 0, 0], [1, 0, 0, 0]], dtype=np.float64))
+    w, od, idg = get_natural_random_walk_matrix(a)
+    w.data[0] = 0.0
+    with _native.Context(w.indptr, w.indices, w.data, od, idg) as ctx:
+        with pytest.raises(_native.ArcteHipError) as e:
+            ctx.run_seeds(np.array([0]), 0.1, 1e-5)
+        assert e.value.code == -5
+        ctx.run_seeds(np.array([1, 2]), 0.1, 1e-5)     # the context stays usable
+    with pytest.raises(RuntimeError):
+        oracle.worker(w, od, idg, np.array([0]), 0.1, 1e-5)
+
+
+def test_config1_rmat_all_seeds_matches_reference_hash():
+    """All 63 070 seeds of the config-1 graph: SHA-256 of the canonical CSR against the reference's own run."""
+    z = np.load(os.path.join(GOLDEN, "rmat100k_summary.npz"))
+    adjacency = rmat_graph(100000, 2000000, seed=0)
+    f = arcte(adjacency, float(z["rho"]), float(z["epsilon"]), 1)
+    f.sum_duplicates()
+    f.sort_indices()
+    assert f.nnz == int(z["nnz"])
+    local = sparse.csc_matrix(f[:, 100000:])
+    assert np.array_equal(np.diff(local.indptr), z["local_col_counts"])
+    h = hashlib.sha256()
+    h.update(f.indptr.astype(np.int64).tobytes())
+    h.update(f.indices.astype(np.int64).tobytes())
+    assert np.array_equal(np.frombuffer(h.digest(), dtype=np.uint8), z["sha256"])

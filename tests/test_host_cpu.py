@@ -1,0 +1,102 @@
+"""CPU-side checks (no GPU): host logic and the C-ABI surface."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import scipy.sparse as sparse
+
+from conftest import ROOT, assert_same_sparse
+
+from reveal_graph_embedding_amd import _native
+from reveal_graph_embedding_amd.eps_randomwalk.transition import get_natural_random_walk_matrix
+from reveal_graph_embedding_amd.embedding.arcte.arcte import parallel_chunks, roundrobin_chunks, seed_nodes
+from reveal_graph_embedding_amd.synthetic import rmat_graph
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "arcte_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(arcte_hip_\w+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = ctypes.CDLL(_native.LIB_PATH)
+    names = header_symbols()
+    assert len(names) >= 15
+    for name in names:
+        assert hasattr(lib, name), name
+    assert sorted(_native.SIGNATURES) == names
+    assert _native.lib().arcte_hip_abi_version() == 1
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    if _native.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    from reveal_graph_embedding_amd.embedding.arcte.arcte import arcte
+    with pytest.raises(_native.ArcteHipError):
+        arcte(sparse.eye(8, format="csr"), 0.1, 1e-5)
+    with pytest.raises(_native.ArcteHipError):
+        _native.Context(np.array([0, 1, 2]), np.array([1, 0]), np.ones(2), np.ones(2), np.ones(2))
+
+
+def test_argument_validation_happens_before_any_device_work():
+    bad = np.array([0, 3, 2], dtype=np.int64)
+    with pytest.raises(_native.ArcteHipError) as e:
+        _native.Context(bad, np.array([1, 0, 1]), np.ones(3), np.ones(2), np.ones(2))
+    assert e.value.code == -1
+    with pytest.raises(_native.ArcteHipError) as e:
+        _native.Context(np.array([0, 1, 2]), np.array([1, 7]), np.ones(2), np.ones(2), np.ones(2))
+    assert e.value.code == -1
+
+
+def test_product_does_not_import_oracle():
+    pkg = os.path.join(ROOT, "reveal-graph-embedding_amd")
+    for base, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(base, f)).read()
+                for needle in ("import oracle", "from oracle", "liboracle", "oracle/", "oracle."):
+                    assert needle not in text, (needle, os.path.join(base, f))
+
+
+def test_transition_matrix_matches_reference_fixture(golden):
+    w, out_degree, in_degree = get_natural_random_walk_matrix(golden["adjacency"])
+    assert_same_sparse(w, golden["w"])
+    assert np.array_equal(out_degree, golden["out_degree"])
+    assert np.array_equal(in_degree, golden["in_degree"])
+    assert w.has_sorted_indices
+
+
+def test_transition_zero_out_degree_rows_and_unsorted_input():
+    a = sparse.coo_matrix((np.array([2.0, 1.0, 4.0]), (np.array([0, 0, 2]), np.array([2, 1, 0]))), shape=(3, 3))
+    w, od, idg = get_natural_random_walk_matrix(a)
+    assert np.array_equal(od, [3.0, 1.0, 4.0])
+    assert np.array_equal(idg, [4.0, 1.0, 2.0])
+    assert np.array_equal(w.toarray(), [[0, 1 / 3.0, 2 / 3.0], [0, 0, 0], [1.0, 0, 0]])
+
+
+def test_chunkers_match_reference_semantics():
+    l = list(range(10))
+    assert list(parallel_chunks(l, 3)) == [[0, 3, 6, 9], [1, 4, 7], [2, 5, 8]]
+    assert roundrobin_chunks([1, 2], 4, 3) is None
+
+
+def test_seed_list_is_count_descending_and_excludes_degree_le_1(golden):
+    a = golden["adjacency"]
+    seeds = seed_nodes(a)
+    cnt = np.bincount(a.indices, minlength=a.shape[0])
+    assert np.array_equal(np.sort(seeds), golden["all_seeds"])
+    assert np.all(np.diff(cnt[seeds]) <= 0)
+    assert np.all(cnt[seeds] > 1)
+
+
+def test_rmat_generator_reproduces_survey_counts():
+    a = rmat_graph(100000, 2000000, seed=0)
+    deg = np.diff(a.indptr)
+    assert a.nnz == 3554220
+    assert int((deg == 0).sum()) == 25004
+    assert int((deg > 1).sum()) == 63070
+    assert int(deg.max()) == 14891
+    assert (a != a.T).nnz == 0
