@@ -1,0 +1,241 @@
+#!/usr/bin/env python3
+"""ARCTE hot-path benchmark: seed-vertices/sec on a synthetic R-MAT power-law graph.
+
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1 is launched by torch.distributed.run (one rank per GPU, backend nccl = RCCL).
+
+Workload (BASELINE.json metric: "seed-vertices/sec ... 1M-node power-law graph", configs[2]/[3]):
+R-MAT n=1,000,000 / 50,000,000 sampled edges (SURVEY.md 8(d) recipe), rho=0.1, eps=1e-5, float64.
+The reference's degree-descending seed list is dealt round-robin into `--shards` (default 8) shards
+exactly as the reference deals it over processes (arcte.py:14-23); rank r of N runs shard r.  One
+STEP = one pass of the whole hot path (effective epsilon -> exact-FIFO eps-push -> community
+extraction -> column-compressed result in HBM) over that shard, inputs resident in HBM, plus -- for
+N > 1 -- the gather of every rank's result on rank 0 over RCCL.  Per-GPU work is fixed as N grows
+("weak"); at N = 8 the step covers every seed of the graph (configs[3]).  `--shards 1` at N = 1 is the
+all-seeds pass of configs[2].
+
+Rank 0 prints ONE JSON line; `roofline` prices the dominant kernel (k_arcte_seeds) by ALGORITHMIC
+bytes (52 B/edge + 36 B/push + 4 B/enqueue + 36 B/support entry, counted by the
+kernel itself) over its HIP-event duration; `cpu_baseline` times the CPU oracle (a C port of the
+reference's algorithm, OpenMP over seeds) on a bounded sample of the same shard.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def algorithmic_bytes(st):
+    return 52 * st["edges"] + 36 * st["pushes"] + 4 * st["enqueues"] + 36 * st["support"]
+
+
+def load_graph(n, m, seed, rank, barrier):
+    """R-MAT adjacency (CSR).  Generated once per node and cached under /tmp for the other ranks/runs."""
+    import scipy.sparse as sparse
+    from reveal_graph_embedding_amd.synthetic import rmat_graph
+    path = "/tmp/arcte_rmat_%d_%d_%d.npz" % (n, m, seed)
+    if not os.path.exists(path) and rank == 0:
+        t = time.time()
+        a = rmat_graph(n, m, seed)
+        tmp = path + ".%d.tmp.npz" % os.getpid()
+        np.savez(tmp, indptr=a.indptr, indices=a.indices)
+        os.replace(tmp, path)
+        log("[bench] generated R-MAT n=%d m=%d nnz=%d in %.1fs" % (n, m, a.nnz, time.time() - t))
+    barrier()
+    z = np.load(path)
+    indices = z["indices"]
+    return sparse.csr_matrix((np.ones(indices.size, dtype=np.float64), indices, z["indptr"]), shape=(n, n))
+
+
+def cpu_baseline(w, out_degree, in_degree, shard, rho, eps, budget_s):
+    from oracle import oracle
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = max(1, min(cores, oracle.lib().oracle_max_threads()))
+    rng = np.random.default_rng(0)
+    count = min(shard.size, 8 * cores)
+    while True:
+        sample = np.sort(rng.choice(shard.size, size=count, replace=False))
+        t = time.perf_counter()
+        _, _, _, _, stats = oracle.worker(w, out_degree, in_degree, shard[sample], rho, eps, threads=cores,
+                                          want_stats=True)
+        dt = max(time.perf_counter() - t, 1e-3)
+        if dt >= 0.6 * budget_s or count >= shard.size:
+            break
+        count = int(min(shard.size, count * min(max(budget_s / dt, 2.0), 16.0)))
+    st = dict(pushes=int(stats[0]), edges=int(stats[1]), enqueues=int(stats[2]), support=int(stats[3]))
+    return {"value": count / dt, "unit": "seeds/s", "cores": cores, "kind": "port",
+            "sample": "%d seeds drawn uniformly from the step's shard, %.1f s, OpenMP over seeds" % (count, dt),
+            "algorithmic_GBps": algorithmic_bytes(st) / dt / 1e9}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--nodes", type=int, default=1000000)
+    ap.add_argument("--edges", type=int, default=50000000)
+    ap.add_argument("--shards", type=int, default=8, help="round-robin shards of the seed list; rank r runs shard r")
+    ap.add_argument("--rho", type=float, default=0.1)
+    ap.add_argument("--epsilon", type=float, default=1e-5)
+    ap.add_argument("--slots", type=int, default=0)
+    ap.add_argument("--gather", choices=["rows", "counts"], default="rows",
+                    help="N>1: what rank 0 collects per step (rows = the full result)")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (0 = skip)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)" % (args.gpus, world))
+    if args.shards < world:
+        raise SystemExit("--shards must be >= the number of GPUs")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    from reveal_graph_embedding_amd import _native
+    from reveal_graph_embedding_amd.distributed import gather_shards, shard_seeds
+    from reveal_graph_embedding_amd.eps_randomwalk.transition import get_natural_random_walk_matrix
+    from reveal_graph_embedding_amd.embedding.arcte.arcte import seed_nodes
+
+    adjacency = load_graph(args.nodes, args.edges, 0, local_rank, barrier)
+    w, out_degree, in_degree = get_natural_random_walk_matrix(adjacency)
+    seeds = seed_nodes(adjacency)
+    shard = shard_seeds(seeds, args.shards, rank)
+    nnz = int(adjacency.nnz)
+    del adjacency
+    ctx = _native.Context(w.indptr, w.indices, w.data, out_degree, in_degree, device=local_rank, n_slots=args.slots)
+    info = ctx.info()
+    log("[bench] rank %d: n=%d nnz=%d seeds=%d shard=%d slots=%d device_bytes=%.1f GB" % (
+        rank, args.nodes, nnz, seeds.size, shard.size, info["slots"], info["device_bytes"] / 1e9))
+
+    gathered_rows = 0
+
+    def step():
+        nonlocal gathered_rows
+        ctx.run_seeds(shard, args.rho, args.epsilon, use_effective_epsilon=True)
+        if world > 1:
+            _, total = ctx.result_sizes()
+            counts_t = torch.from_numpy(np.diff(ctx.colptr())).to(dev)
+            if args.gather == "rows":
+                rows_t = torch.empty(total, dtype=torch.int32, device=dev)
+                ctx.copy_rows_to_device(rows_t.data_ptr(), total)
+            else:
+                rows_t = torch.empty(0, dtype=torch.int32, device=dev)
+            out = gather_shards(counts_t, rows_t, dst=0)
+            if out is not None:
+                gathered_rows = sum(int(r.numel()) for _, r in out)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    push_ms = 0.0
+    for _ in range(args.steps):
+        step()
+        push_ms += ctx.timing()["push_ms"]
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+        nseeds_t = torch.tensor([shard.size], dtype=torch.int64, device=dev)
+        dist.all_reduce(nseeds_t, op=dist.ReduceOp.SUM)
+        seeds_per_step = int(nseeds_t.item())
+    else:
+        seeds_per_step = int(shard.size)
+
+    st = ctx.stats()
+    tm = ctx.timing()
+    _, total_rows = ctx.result_sizes()
+    if rank == 0:
+        alg = algorithmic_bytes(st)
+        kernel_ms = push_ms / max(args.steps, 1)
+        achieved = alg / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        traffic = None
+        pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc_path):
+            try:
+                pmc = json.load(open(pmc_path))
+                key = "n%d_m%d_shards%d" % (args.nodes, args.edges, args.shards)
+                if key in pmc:
+                    traffic = pmc[key]["hbm_bytes_per_launch"]
+            except Exception:
+                traffic = None
+        result = {
+            "metric": "seed-vertices/sec",
+            "value": seeds_per_step * args.steps / elapsed,
+            "unit": "seeds/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / max(args.steps, 1) * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": "R-MAT n=%d m=%d (nnz %d, %d seeds), rho=%g eps=%g; step = seed shard %s of %d (round-robin "
+                            "over the degree-descending seed list) per GPU through eps_eff -> eps-push -> extraction%s"
+                            % (args.nodes, args.edges, nnz, seeds.size, args.rho, args.epsilon,
+                               "r" if world > 1 else "0", args.shards,
+                               " + RCCL gather of %s on rank 0" % args.gather if world > 1 else ""),
+                "seeds_per_step": seeds_per_step,
+                "shards": args.shards,
+                "slots_per_gpu": info["slots"],
+                "emitted_rows_rank0": int(total_rows),
+                "gathered_rows_rank0": int(gathered_rows),
+                "per_seed": {k: st[k] / max(shard.size, 1) for k in ("pushes", "edges", "enqueues", "support")},
+                "reruns": st["reruns"],
+                "eps_kernel_ms": tm["eps_ms"], "compact_ms": tm["compact_ms"], "call_ms": tm["call_ms"],
+            },
+            "roofline": {
+                "bound": "hbm", "kernel": "k_arcte_seeds<0>",
+                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic,
+                "algorithmic_bytes_per_launch": alg, "kernel_ms_per_launch": kernel_ms,
+            },
+        }
+        if world == 1 and args.cpu_seconds > 0:
+            result["cpu_baseline"] = cpu_baseline(w, out_degree, in_degree, shard, args.rho, args.epsilon, args.cpu_seconds)
+        else:
+            result["cpu_baseline"] = None
+        print(json.dumps(result), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -98,6 +98,10 @@ int arcte_hip_fetch_result(arcte_hip_ctx *ctx, int64_t *colptr, int32_t *rows,
  * (RCCL); valid until the next run on this context. */
 int arcte_hip_result_device_rows(arcte_hip_ctx *ctx, void **rows_dev);
 
+/* Copy the last run's rows (int32[total_rows]) into caller-owned DEVICE memory on the same GPU
+ * (e.g. a tensor that a RCCL collective will send); device-to-device, no host round trip. */
+int arcte_hip_copy_result_rows_to_device(arcte_hip_ctx *ctx, void *dst_dev, int64_t capacity_rows);
+
 /*
  * Work counters of the last run, summed over its seeds:
  * stats[0] pushes, [1] edges traversed, [2] enqueues, [3] support entries,

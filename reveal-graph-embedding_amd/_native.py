@@ -29,6 +29,7 @@ SIGNATURES = {
     "arcte_hip_result_sizes": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "arcte_hip_fetch_result": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "arcte_hip_result_device_rows": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "arcte_hip_copy_result_rows_to_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "arcte_hip_run_stats": (C.c_int, [C.c_void_p, _i64p]),
     "arcte_hip_run_timing": (C.c_int, [C.c_void_p, _f64p]),
     "arcte_hip_similarity_slice": (C.c_int, [C.c_void_p, C.c_int64, C.c_double, C.c_double, _f64p, _f64p,
@@ -149,6 +150,16 @@ class Context:
         p = C.c_void_p()
         _check(lib().arcte_hip_result_device_rows(self._h, C.byref(p)))
         return p.value or 0
+
+    def copy_rows_to_device(self, device_ptr, capacity_rows):
+        """Device-to-device copy of the last run's rows into e.g. a torch tensor (tensor.data_ptr())."""
+        _check(lib().arcte_hip_copy_result_rows_to_device(self._h, C.c_void_p(int(device_ptr)), int(capacity_rows)))
+
+    def colptr(self):
+        ns, _ = self.result_sizes()
+        colptr = np.zeros(ns + 1, dtype=np.int64)
+        _check(lib().arcte_hip_fetch_result(self._h, colptr.ctypes.data, None, None, None))
+        return colptr
 
     def stats(self):
         s = np.zeros(6, dtype=np.int64)

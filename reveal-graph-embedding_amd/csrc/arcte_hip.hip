@@ -579,6 +579,7 @@ struct arcte_hip_ctx {
     DevBuf<int64_t> out_off, dst_off;
     DevBuf<unsigned long long> counters;   // [0] work counter [1] raw cursor [2..6] stats
     DevBuf<int32_t> raw, rows_final;
+    int64_t raw_for_seeds = 0;
     int64_t final_rows = 0;
     std::vector<int64_t> colptr;
     int64_t stats[6] = {0, 0, 0, 0, 0, 0};
@@ -831,11 +832,15 @@ int arcte_hip_run_seeds(arcte_hip_ctx *c, const int64_t *seeds, int64_t nseeds, 
     HIP_TRY(hipEventRecord(c->ev[1], c->stream));
 
     // raw arena: grows on demand (seeds that did not fit are re-run)
-    if (c->raw.count == 0) {
+    if (c->raw.count < (size_t)c->n || c->raw_for_seeds < nseeds) {
+        c->raw.release();
+        c->raw_for_seeds = nseeds;
         size_t free_b = 0, total_b = 0;
         HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-        size_t want = std::max<size_t>((size_t)c->n, std::min<size_t>((size_t)nseeds * 1024, (size_t)1 << 30));
-        want = std::min(want, std::max<size_t>((size_t)c->n, free_b / 16));
+        // 4096 rows per seed is ~3x what power-law graphs emit on average; the arena is reused by later
+        // runs and re-filled (failed seeds re-run) when it is still too small
+        size_t want = std::max<size_t>((size_t)c->n, std::min<size_t>((size_t)nseeds * 4096, (size_t)1 << 32));
+        want = std::min(want, std::max<size_t>((size_t)c->n, free_b / 4 / sizeof(int32_t)));
         if (const char *env = getenv("ARCTE_HIP_ARENA_ROWS")) {   // test hook: force a small arena
             long long v = atoll(env);
             if (v > 0) want = std::max<size_t>((size_t)c->n, (size_t)v);
@@ -1021,6 +1026,19 @@ int arcte_hip_result_device_rows(arcte_hip_ctx *c, void **rows_dev)
     if (!c || !rows_dev) return fail(ARCTE_HIP_EINVAL, "bad argument");
     if (c->run_nseeds < 0) return fail(ARCTE_HIP_ESTATE, "no completed run on this context");
     *rows_dev = c->rows_final.p;
+    return 0;
+}
+
+int arcte_hip_copy_result_rows_to_device(arcte_hip_ctx *c, void *dst_dev, int64_t capacity_rows)
+{
+    if (!c || (!dst_dev && capacity_rows)) return fail(ARCTE_HIP_EINVAL, "bad argument");
+    if (c->run_nseeds < 0) return fail(ARCTE_HIP_ESTATE, "no completed run on this context");
+    if (capacity_rows < c->final_rows) return fail(ARCTE_HIP_EINVAL, "destination too small");
+    HIP_TRY(hipSetDevice(c->device));
+    if (c->final_rows) {
+        HIP_TRY(hipMemcpyAsync(dst_dev, c->rows_final.p, c->final_rows * sizeof(int32_t), hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
     return 0;
 }
 

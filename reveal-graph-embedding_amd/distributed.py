@@ -1,0 +1,129 @@
+"""Seed sharding over the GPUs of one node: one process per GPU, torch.distributed as the transport.
+
+The reference's only parallelism is data parallelism over seed vertices with a final sum of disjoint
+columns (embedding/arcte/arcte.py:650-673).  Here the read-only transition matrix is replicated on
+every GPU, rank k owns seeds[k::world] of the degree-descending seed list (the reference's
+round-robin chunks, arcte.py:14-23), and the only communication is one variable-length gather of
+the emitted rows to rank 0 (RCCL over xGMI when the tensors are on the GPU).
+"""
+import numpy as np
+import scipy.sparse as sparse
+
+
+def shard_seeds(seeds, world_size, rank):
+    """Chunk `rank` of parallel_chunks(seeds, world_size) (arcte.py:14-23) as an int64 array."""
+    return np.ascontiguousarray(np.asarray(seeds, dtype=np.int64)[rank::world_size])
+
+
+def gather_shards(counts, rows, dst=0, group=None):
+    """Gather every rank's column-compressed result on `dst`.
+
+    counts: 1-D int64 tensor (community size per local seed), rows: 1-D int32 tensor (their members,
+    concatenated).  Both live on the device the process group communicates on (GPU for nccl/RCCL,
+    CPU for gloo).  Returns on dst a list [(counts_k, rows_k) for k in range(world)], None elsewhere.
+    Sizes travel in one all_gather; the payload moves as point-to-point sends to dst only.
+    """
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    sizes = torch.tensor([counts.numel(), rows.numel()], dtype=torch.int64, device=counts.device)
+    all_sizes = [torch.zeros_like(sizes) for _ in range(world)]
+    dist.all_gather(all_sizes, sizes, group=group)
+    all_sizes = [tuple(int(x) for x in t.tolist()) for t in all_sizes]
+    if rank == dst:
+        out = []
+        ops = []
+        for k in range(world):
+            if k == dst:
+                out.append((counts, rows))
+                continue
+            ck = torch.empty(all_sizes[k][0], dtype=counts.dtype, device=counts.device)
+            rk = torch.empty(all_sizes[k][1], dtype=rows.dtype, device=rows.device)
+            out.append((ck, rk))
+            if ck.numel():
+                ops.append(dist.P2POp(dist.irecv, ck, k, group))
+            if rk.numel():
+                ops.append(dist.P2POp(dist.irecv, rk, k, group))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        return out
+    ops = []
+    if counts.numel():
+        ops.append(dist.P2POp(dist.isend, counts, dst, group))
+    if rows.numel():
+        ops.append(dist.P2POp(dist.isend, rows, dst, group))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    return None
+
+
+def merge_shards(n, seeds, world_size, gathered):
+    """Rank-0 side of the reference's `sum of worker results` (arcte.py:670-673): every seed owns its
+    column, so the sum is a concatenation.  Returns the n x n CSR of local communities."""
+    seeds = np.asarray(seeds, dtype=np.int64)
+    row_parts, col_parts = [], []
+    for k, (counts, rows) in enumerate(gathered):
+        counts = np.asarray(counts.cpu().numpy() if hasattr(counts, "cpu") else counts, dtype=np.int64)
+        rows = np.asarray(rows.cpu().numpy() if hasattr(rows, "cpu") else rows)
+        shard = seeds[k::world_size]
+        if counts.size != shard.size:
+            raise ValueError("rank %d returned %d seeds, expected %d" % (k, counts.size, shard.size))
+        row_parts.append(rows.astype(np.int64))
+        col_parts.append(np.repeat(shard, counts))
+    rows = np.concatenate(row_parts) if row_parts else np.zeros(0, np.int64)
+    cols = np.concatenate(col_parts) if col_parts else np.zeros(0, np.int64)
+    m = sparse.coo_matrix((np.ones(rows.size, dtype=np.float64), (rows, cols)), shape=(n, n))
+    return sparse.csr_matrix(m)
+
+
+def arcte_distributed(adjacency_matrix, rho, epsilon, device=None, group=None, run_shard=None):
+    """arcte() (arcte.py:591-688) with the seeds sharded over the ranks of `group`.
+
+    Must be called by every rank with the same adjacency matrix.  Rank 0 returns the n x 2n feature
+    matrix, the others None.  `run_shard(w, out_degree, in_degree, seeds, rho, epsilon) -> (colptr,
+    rows)` overrides the compute step (the CPU multi-process tests plug a checker in here); the
+    default runs the HIP path on GPU `device` (default: LOCAL_RANK).
+    """
+    import os
+    import torch
+    import torch.distributed as dist
+    from reveal_graph_embedding_amd.eps_randomwalk.transition import get_natural_random_walk_matrix
+    from reveal_graph_embedding_amd.embedding.arcte.arcte import seed_nodes
+
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    adjacency_matrix = sparse.csr_matrix(adjacency_matrix)
+    n = adjacency_matrix.shape[0]
+    w, out_degree, in_degree = get_natural_random_walk_matrix(adjacency_matrix)
+    seeds = seed_nodes(adjacency_matrix)
+    mine = shard_seeds(seeds, world, rank)
+
+    if run_shard is not None:
+        colptr, rows = run_shard(w, out_degree, in_degree, mine, rho, epsilon)
+        counts_t = torch.from_numpy(np.diff(colptr).astype(np.int64))
+        rows_t = torch.from_numpy(np.ascontiguousarray(rows, dtype=np.int32))
+        if dist.get_backend(group) == "nccl":
+            counts_t, rows_t = counts_t.cuda(), rows_t.cuda()
+    else:
+        from reveal_graph_embedding_amd import _native
+        if device is None:
+            device = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(device)
+        with _native.Context(w.indptr, w.indices, w.data, out_degree, in_degree, device=device) as ctx:
+            ctx.run_seeds(mine, rho, epsilon, use_effective_epsilon=True)
+            _, total = ctx.result_sizes()
+            counts_t = torch.from_numpy(np.diff(ctx.colptr())).to("cuda:%d" % device)
+            rows_t = torch.empty(total, dtype=torch.int32, device="cuda:%d" % device)
+            ctx.copy_rows_to_device(rows_t.data_ptr(), total)
+    gathered = gather_shards(counts_t, rows_t, dst=0, group=group)
+    if rank != 0:
+        return None
+    local = merge_shards(n, seeds, world, gathered)
+    identity = sparse.csr_matrix(sparse.eye(n, n, dtype=np.float64))
+    ones = adjacency_matrix.copy()
+    ones.data = np.ones_like(ones.data, dtype=np.float64)
+    return sparse.hstack([identity + ones, local]).tocsr()
