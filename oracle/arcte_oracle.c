@@ -116,6 +116,10 @@ typedef struct {
     int64_t pushes, edges, enqueues, support;
 } oracle_stats_t;
 
+/* optional recording of the pushed node ids, in push order (analysis aid for the kernel design) */
+static __thread int32_t *g_trace = 0;
+static __thread int64_t g_trace_cap = 0, g_trace_len = 0;
+
 /* first-touch bookkeeping: `touched` receives every index whose s went 0 -> nonzero */
 static inline void deposit(double *s, double *r, int32_t v, double p, int32_t *touched, int64_t *ntouched)
 {
@@ -147,6 +151,7 @@ static int64_t similarity_core(const int64_t *indptr, const int32_t *indices, co
         if (first || r[u] / in_degree[u] >= epsilon) {
             double commute = (1 - rho) * r[u];               /* push.py:56 */
             r[u] = 0.0;                                      /* push.py:59 */
+            if (g_trace) { if (g_trace_len < g_trace_cap) g_trace[g_trace_len] = (int32_t)u; g_trace_len++; }
             int64_t b = indptr[u], e = indptr[u + 1];
             for (int64_t k = b; k < e; k++)                  /* push.py:62-64 */
                 deposit(s, r, indices[k], commute * data[k], touched, ntouched);
@@ -317,6 +322,27 @@ int oracle_worker(int64_t n, const int64_t *indptr, const int32_t *indices, cons
     *rows_io = rows;
     if (stats4) { stats4[0] = total.pushes; stats4[1] = total.edges; stats4[2] = total.enqueues; stats4[3] = total.support; }
     return status;
+}
+
+/* Pushed node ids of one seed run with its effective epsilon (arcte.py:340-350); returns the push
+ * count (may exceed cap, in which case the trace is truncated). */
+int64_t oracle_push_trace(int64_t n, const int64_t *indptr, const int32_t *indices, const double *data,
+                          const double *out_degree, const double *in_degree, int64_t seed, double rho,
+                          double epsilon, int32_t *trace, int64_t cap)
+{
+    double *s = (double *)calloc((size_t)n, sizeof(double));
+    double *r = (double *)calloc((size_t)n, sizeof(double));
+    int64_t b = indptr[seed], deg = indptr[seed + 1] - b;
+    double *nd = (double *)malloc((size_t)(deg + 1) * sizeof(double));
+    for (int64_t k = 0; k < deg; k++) nd[k] = out_degree[indices[b + k]];
+    double eps_eff = oracle_epsilon_effective(epsilon, out_degree[seed], nd, deg);
+    fifo_t q = {0, 0, 0, 0};
+    g_trace = trace; g_trace_cap = cap; g_trace_len = 0;
+    similarity_core(indptr, indices, data, in_degree, seed, rho, eps_eff, s, r, &q, 0, 0, 0);
+    int64_t len = g_trace_len;
+    g_trace = 0;
+    free(q.buf); free(s); free(r); free(nd);
+    return len;
 }
 
 void oracle_free(void *p) { free(p); }

@@ -52,6 +52,9 @@ def lib():
         l.oracle_worker.argtypes = [C.c_int64, _i64p, _i32p, _f64p, _f64p, _f64p, _i64p, C.c_int64,
                                     C.c_double, C.c_double, C.c_int, _i64p, C.POINTER(C.POINTER(C.c_int32)),
                                     C.c_void_p, C.c_void_p, C.c_void_p]
+        l.oracle_push_trace.restype = C.c_int64
+        l.oracle_push_trace.argtypes = [C.c_int64, _i64p, _i32p, _f64p, _f64p, _f64p, C.c_int64, C.c_double, C.c_double,
+                                        _i32p, C.c_int64]
         l.oracle_free.restype = None
         l.oracle_free.argtypes = [C.c_void_p]
         l.oracle_max_threads.restype = C.c_int
@@ -116,6 +119,17 @@ def worker(w, out_degree, in_degree, seeds, rho, epsilon, threads=1, want_stats=
     if want_stats:
         return colptr, rows, eps_eff, nop, stats
     return colptr, rows
+
+
+def push_trace(w, out_degree, in_degree, seed, rho, epsilon, cap=1 << 16):
+    """Node ids pushed for `seed` (effective epsilon), in push order."""
+    indptr, indices, data = _csr_arrays(w)
+    buf = np.zeros(cap, dtype=np.int32)
+    n = lib().oracle_push_trace(w.shape[0], indptr, indices, data,
+                                np.ascontiguousarray(out_degree, dtype=np.float64),
+                                np.ascontiguousarray(in_degree, dtype=np.float64), int(seed), float(rho), float(epsilon),
+                                buf, cap)
+    return buf[:min(n, cap)].copy()
 
 
 def worker_matrix(w, out_degree, in_degree, seeds, rho, epsilon, threads=1):

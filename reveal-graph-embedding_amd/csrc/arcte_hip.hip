@@ -3,9 +3,11 @@
 // One 64-lane wavefront owns one seed at a time ("slot"): it runs the reference's strictly
 // sequential FIFO of similarity.py:149-222 exactly, and spends its 64 lanes on the edges of
 // the row being pushed (push.py:62-64: distinct targets, no conflicts).  Thousands of slots
-// are in flight per GPU, each with a private dense {r, s} vector in HBM, so the chip is kept
-// busy by seed-level parallelism while every seed keeps the reference's operation order --
-// which is what makes the output sparsity pattern bit-exact.
+// are in flight per GPU, each with a private dense state vector in HBM (32-byte entries
+// {r, s, in_degree, epoch}: one 32-B sector per touched node, validity by epoch tag so nothing
+// is ever zero-filled between seeds), so the chip is kept busy by seed-level parallelism while
+// every seed keeps the reference's operation order -- which is what makes the output sparsity
+// pattern bit-exact.
 //
 // Arithmetic notes (all pinned by tests against the CPU oracle):
 //   - built with -ffp-contract=off: p = c*w then s+p, r+p are separate IEEE operations as in
@@ -89,6 +91,7 @@ struct GraphDev {
     const double *data;
     const double *out_degree;
     const double *in_degree;
+    const double *edge_in_degree;   // in_degree[indices[k]] stored with the edge: streams with the row
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -209,6 +212,34 @@ __global__ __launch_bounds__(BLOCK) void k_epsilon_effective(GraphDev g, const i
 // a2 + a3 + a5: per-seed FIFO propagation and community extraction
 // ---------------------------------------------------------------------------------------------
 
+// Dense per-slot state, one 32-byte sector per node.  An entry is live only while its epoch equals
+// the slot's current epoch (one epoch per seed), so "s[:] = 0; r[:] = 0" (arcte.py:337-338) costs
+// nothing and first touches are recognised without a separate bitmap.
+struct __attribute__((aligned(32))) Entry {
+    double r;
+    double s;
+    double d;         // in_degree of the node (threshold tests and the degree normalisation)
+    uint32_t epoch;
+    uint32_t pad;
+};
+static_assert(sizeof(Entry) == 32, "Entry must be one 32-byte sector");
+
+struct EntryLo { double r, s; };
+struct EntryHi { double d; uint32_t epoch, pad; };
+
+__device__ __forceinline__ EntryLo load_lo(const Entry *e) { double2 t = *reinterpret_cast<const double2 *>(e); return {t.x, t.y}; }
+__device__ __forceinline__ EntryHi load_hi(const Entry *e)
+{
+    double2 t = *(reinterpret_cast<const double2 *>(e) + 1);
+    uint64_t bits = (uint64_t)__double_as_longlong(t.y);
+    return {t.x, (uint32_t)bits, (uint32_t)(bits >> 32)};
+}
+__device__ __forceinline__ void store_lo(Entry *e, double r, double s) { *reinterpret_cast<double2 *>(e) = make_double2(r, s); }
+__device__ __forceinline__ void store_hi(Entry *e, double d, uint32_t epoch)
+{
+    *(reinterpret_cast<double2 *>(e) + 1) = make_double2(d, __longlong_as_double((long long)(uint64_t)epoch));
+}
+
 struct PushParams {
     GraphDev g;
     // work list
@@ -219,9 +250,10 @@ struct PushParams {
     const double *eps;
     double one_minus_rho;
     // per-slot scratch
-    double2 *rs;       // [slots][n]  {x = r, y = s}
+    Entry *state;      // [slots][n]
+    uint32_t *slot_epoch;   // [slots] last epoch used by the slot
     int32_t *queue;    // [slots][qcap]
-    int32_t *sup;      // [slots][n]   first-touch list = support of s
+    int32_t *sup;      // [slots][n]   first-touch list
     uint32_t qcap;     // power of two
     int32_t max_pushes; // per-seed cap, see ST_RUNAWAY
     // outputs
@@ -235,8 +267,8 @@ struct PushParams {
     unsigned long long *stats;   // [0] pushes [1] edges [2] enqueues [3] support [4] failed seeds
 };
 
-// MODE 0: full arcte_worker body (extract + reset).  MODE 1: similarity slice only, the slot's
-// dense vectors are left for the host to read back.
+// MODE 0: full arcte_worker body (extract).  MODE 1: similarity slice only on the dense vectors the
+// host placed in slot 0 (k_state_from_dense), left there for k_state_to_dense.
 template <int MODE>
 __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
 {
@@ -244,11 +276,12 @@ __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
     const int wave = threadIdx.x >> 6;
     const int64_t slot = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wave;
     const GraphDev &g = P.g;
-    double2 *__restrict__ rs = P.rs + slot * g.n;
+    Entry *__restrict__ st = P.state + slot * g.n;
     int32_t *__restrict__ q = P.queue + slot * (int64_t)P.qcap;
     int32_t *__restrict__ sup = P.sup + slot * g.n;
     const uint32_t qmask = P.qcap - 1;
     const double omr = P.one_minus_rho;
+    uint32_t epoch = P.slot_epoch[slot];
 
     // Dynamic seed queue: lane 0 draws the next work item, the wave broadcasts it.  The
     // wave_barrier (convergent, emits nothing) keeps LLVM's jump threading from fusing this
@@ -280,6 +313,7 @@ __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
                 continue;
             }
         }
+        epoch++;                           // every entry of the previous seed is stale from here on
 
         uint32_t head = 0, tail = 0;       // ring counters (wave-uniform)
         int32_t nsup = 0;
@@ -291,31 +325,36 @@ __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
         //      similarity.py:194-196 / :214-216.  `ru` is r[u] at pop time.
         auto push = [&](int32_t u, double ru, int64_t rb, int64_t re) {
             const double c = omr * ru;                       // push.py:56
-            if (lane == 0) rs[u].x = 0.0;                    // push.py:59
+            if (lane == 0) st[u].r = 0.0;                    // push.py:59
             for (int64_t base = rb; base < re; base += 2 * WAVE) {
                 const int64_t k0 = base + lane, k1 = k0 + WAVE;
                 const bool a0 = k0 < re, a1 = k1 < re;
                 int32_t v0 = 0, v1 = 0;
-                double w0 = 0.0, w1 = 0.0;
-                if (a0) { v0 = g.indices[k0]; w0 = g.data[k0]; }
-                if (a1) { v1 = g.indices[k1]; w1 = g.data[k1]; }
-                double2 g0 = make_double2(0.0, 0.0), g1 = make_double2(0.0, 0.0);
-                double d0 = 1.0, d1 = 1.0;
-                if (a0) { g0 = rs[v0]; d0 = g.in_degree[v0]; }
-                if (a1) { g1 = rs[v1]; d1 = g.in_degree[v1]; }
+                double w0 = 0.0, w1 = 0.0, d0 = 1.0, d1 = 1.0;
+                if (a0) { v0 = g.indices[k0]; w0 = g.data[k0]; d0 = g.edge_in_degree[k0]; }
+                if (a1) { v1 = g.indices[k1]; w1 = g.data[k1]; d1 = g.edge_in_degree[k1]; }
+                EntryLo l0 = {0.0, 0.0}, l1 = {0.0, 0.0};
+                EntryHi h0 = {1.0, 0u, 0u}, h1 = {1.0, 0u, 0u};
+                if (a0) { l0 = load_lo(st + v0); h0 = load_hi(st + v0); }
+                if (a1) { l1 = load_lo(st + v1); h1 = load_hi(st + v1); }
 #pragma unroll
                 for (int t = 0; t < 2; t++) {
                     const bool act = t ? a1 : a0;
                     const int32_t v = t ? v1 : v0;
                     const double w = t ? w1 : w0;
-                    const double2 gv = t ? g1 : g0;
                     const double dv = t ? d1 : d0;
+                    const EntryLo lo = t ? l1 : l0;
+                    const bool live = (t ? h1.epoch : h0.epoch) == epoch;
                     const double p = c * w;                                  // push.py:62
-                    const double r_old = (v == u) ? 0.0 : gv.x;              // self-loop sees r[u] = 0
+                    const double r_old = (live && v != u) ? lo.r : 0.0;      // self-loop sees r[u] = 0
+                    const double s_old = live ? lo.s : 0.0;
                     const double r_new = r_old + p;                          // push.py:64
-                    const double s_new = gv.y + p;                           // push.py:63
-                    if (act) rs[v] = make_double2(r_new, s_new);
-                    const bool first = act && gv.y == 0.0 && s_new != 0.0;   // support grows
+                    const double s_new = s_old + p;                          // push.py:63
+                    if (act) {
+                        store_lo(st + v, r_new, s_new);
+                        if (!live) store_hi(st + v, dv, epoch);
+                    }
+                    const bool first = act && !live;                         // the touched list grows
                     const uint64_t mf = __ballot(first);
                     if (first) sup[nsup + lane_below(mf)] = v;
                     nsup += __popcll(mf);
@@ -339,7 +378,12 @@ __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
 
         // ---- similarity.py:176-192: s[seed] = r[seed] = 1, one unconditional push
         if (lane == 0) {
-            rs[seed] = make_double2(1.0, 1.0);
+            if (MODE == 0) {
+                store_lo(st + seed, 1.0, 1.0);
+                store_hi(st + seed, g.in_degree[seed], epoch);
+            } else {
+                store_lo(st + seed, 1.0, 1.0);     // the host made every entry live (caller's s, r)
+            }
             sup[0] = seed;
         }
         nsup = 1;
@@ -358,8 +402,8 @@ __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
             int64_t rb_l = 0, re_l = 0;
             if (valid) {
                 u_l = q[(head + lane) & qmask];
-                r_l = rs[u_l].x;
-                d_l = g.in_degree[u_l];
+                r_l = st[u_l].r;              // queued nodes were deposited to in this epoch: live
+                d_l = st[u_l].d;
                 rb_l = g.indptr[u_l];
                 re_l = g.indptr[u_l + 1];
             }
@@ -377,81 +421,75 @@ __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
                 consumed = i + 1;
                 push(u, ru, rb, re);
                 if (!ok) break;
-                if (valid && lane >= consumed) r_l = rs[u_l].x;
+                if (valid && lane >= consumed) r_l = st[u_l].r;
             }
         }
 
         // ---- arcte.py:352-376: degree-normalise, threshold = min over the closed neighbourhood,
-        //      select everything at or above it, emit iff larger than the base community
-        int32_t st = ok ? ST_OK : (runaway ? ST_RUNAWAY : ST_QUEUE_OVERFLOW);
-        int32_t emitted = 0;
+        //      select everything at or above it, emit iff larger than the base community.
+        //      One pass over the touched list: selected nodes are compacted in place, then copied.
+        int32_t sta = ok ? ST_OK : (runaway ? ST_RUNAWAY : ST_QUEUE_OVERFLOW);
+        int32_t emitted = 0, support = 0;
         unsigned long long off = 0;
         if (MODE == 0 && ok) {
             const int64_t sb = g.indptr[seed], se = g.indptr[seed + 1];
-            double thr = rs[seed].y / g.in_degree[seed];
+            double thr = st[seed].s / st[seed].d;
             bool miss = false;
             for (int64_t k = sb + lane; k < se; k += WAVE) {
                 const int32_t v = g.indices[k];
-                const double sv = rs[v].y;
+                const EntryLo lo = load_lo(st + v);
+                const EntryHi hi = load_hi(st + v);
+                const double sv = (hi.epoch == epoch) ? lo.s : 0.0;
                 miss |= (sv == 0.0);
-                const double x = sv / g.in_degree[v];
+                const double x = sv / g.edge_in_degree[k];
                 thr = (x < thr) ? x : thr;
             }
             thr = wave_min(thr);
-            if (__ballot(miss) != 0) st = ST_MISSING_BASE;
+            if (__ballot(miss) != 0) sta = ST_MISSING_BASE;
             else {
                 int32_t cnt = 0;
                 for (int32_t i0 = 0; i0 < nsup; i0 += WAVE) {
                     const int32_t i = i0 + lane;
-                    bool sel = false;
+                    bool sel = false, nz = false;
+                    int32_t v = 0;
                     if (i < nsup) {
-                        const int32_t v = sup[i];
-                        sel = (rs[v].y / g.in_degree[v]) >= thr;
+                        v = sup[i];
+                        const double sv = st[v].s;
+                        nz = sv != 0.0;                                   // csr_matrix(s) keeps non-zeros only
+                        sel = nz && (sv / st[v].d >= thr);
                     }
-                    cnt += __popcll(__ballot(sel));
+                    const uint64_t ms = __ballot(sel);
+                    if (sel) sup[cnt + lane_below(ms)] = v;               // in place: cnt <= i0
+                    cnt += __popcll(ms);
+                    support += __popcll(__ballot(nz));
                 }
                 if ((int64_t)cnt > (se - sb) + 1) {                                   // arcte.py:370
                     if (lane == 0) off = atomicAdd(P.raw_cursor, (unsigned long long)cnt);
                     off = bcast_u64(off);
-                    if (off + (unsigned long long)cnt > P.rawcap) st = ST_OUTPUT_OVERFLOW;
+                    if (off + (unsigned long long)cnt > P.rawcap) sta = ST_OUTPUT_OVERFLOW;
                     else {
-                        int32_t w = 0;
-                        for (int32_t i0 = 0; i0 < nsup; i0 += WAVE) {
-                            const int32_t i = i0 + lane;
-                            bool sel = false;
-                            int32_t v = 0;
-                            if (i < nsup) {
-                                v = sup[i];
-                                sel = (rs[v].y / g.in_degree[v]) >= thr;
-                            }
-                            const uint64_t ms = __ballot(sel);
-                            if (sel) P.raw[off + w + lane_below(ms)] = v;
-                            w += __popcll(ms);
-                        }
+                        for (int32_t i = lane; i < cnt; i += WAVE) P.raw[off + i] = sup[i];
                         emitted = cnt;
                     }
                 }
             }
         }
-        if (MODE == 0) {
-            // arcte.py:337-338 (s[:] = 0, r[:] = 0) restricted to what was touched
-            for (int32_t i = lane; i < nsup; i += WAVE) rs[sup[i]] = make_double2(0.0, 0.0);
-        }
         if (lane == 0) {
-            P.status[pos] = st;
+            P.status[pos] = sta;
             P.out_cnt[pos] = emitted;
             P.out_off[pos] = (int64_t)off;
             P.nop[pos] = npush;
-            if (st == ST_OK) {
+            if (sta == ST_OK) {
                 atomicAdd(&P.stats[0], (unsigned long long)npush);
                 atomicAdd(&P.stats[1], nedges);
                 atomicAdd(&P.stats[2], (unsigned long long)tail);
-                atomicAdd(&P.stats[3], (unsigned long long)nsup);
+                atomicAdd(&P.stats[3], (unsigned long long)support);
             } else {
                 atomicAdd(&P.stats[4], 1ULL);
             }
         }
     }
+    if (lane == 0) P.slot_epoch[slot] = epoch;
 }
 
 // copy per-seed segments src[src_off[p] .. +cnt[p]) -> dst[dst_off[p] ..), one wavefront per segment;
@@ -470,16 +508,34 @@ __global__ __launch_bounds__(BLOCK) void k_gather_segments(const int32_t *src, c
     for (int32_t i = lane; i < c; i += WAVE) d[i] = s[i];
 }
 
-__global__ void k_interleave(const double *s, const double *r, double2 *rs, int64_t n)
+// caller's dense s, r -> slot 0, every entry live in the epoch the slice kernel is about to use
+__global__ void k_state_from_dense(const double *s, const double *r, const double *in_degree, Entry *st,
+                                   const uint32_t *slot_epoch, int64_t n)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) rs[i] = make_double2(r[i], s[i]);
+    if (i < n) {
+        store_lo(st + i, r[i], s[i]);
+        store_hi(st + i, in_degree[i], slot_epoch[0] + 1);
+    }
 }
 
-__global__ void k_deinterleave(const double2 *rs, double *s, double *r, int64_t n)
+// slot 0 -> dense s, r (slot_epoch[0] is the epoch the slice kernel just used)
+__global__ void k_state_to_dense(const Entry *st, const uint32_t *slot_epoch, double *s, double *r, int64_t n)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) { double2 v = rs[i]; r[i] = v.x; s[i] = v.y; }
+    if (i < n) {
+        const EntryLo lo = load_lo(st + i);
+        const bool live = load_hi(st + i).epoch == slot_epoch[0];
+        r[i] = live ? lo.r : 0.0;
+        s[i] = live ? lo.s : 0.0;
+    }
+}
+
+// in_degree[indices[k]] for every stored edge
+__global__ void k_edge_in_degree(const int32_t *indices, const double *in_degree, double *out, int64_t nnz)
+{
+    int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < nnz) out[k] = in_degree[indices[k]];
 }
 
 // push.py:41-64 on dense device vectors, one workgroup
@@ -549,11 +605,20 @@ int32_t max_pushes_limit()
     return 1 << 26;
 }
 
+uint32_t next_pow2(uint64_t x);
+// The FIFO holds a few hundred entries for typical seeds; an overflowing seed is re-run with a 4x ring.
+uint32_t default_queue_capacity(int64_t n);
+
 uint32_t next_pow2(uint64_t x)
 {
     uint64_t p = 1;
     while (p < x) p <<= 1;
     return (uint32_t)std::min<uint64_t>(p, 1ull << 31);
+}
+
+uint32_t default_queue_capacity(int64_t n)
+{
+    return std::min<uint32_t>(1u << 20, std::max<uint32_t>(4096u, next_pow2((uint64_t)std::max<int64_t>(n / 16, 1))));
 }
 
 }  // namespace
@@ -566,12 +631,14 @@ struct arcte_hip_ctx {
     int64_t n = 0, nnz = 0;
     DevBuf<int64_t> indptr;
     DevBuf<int32_t> indices;
-    DevBuf<double> data, out_degree, in_degree;
+    DevBuf<double> data, out_degree, in_degree, edge_in_degree;
     // slots
     int64_t slots = 0;
     uint32_t qcap = 0;
-    DevBuf<double2> rs;
+    DevBuf<Entry> state;
+    DevBuf<uint32_t> slot_epoch;
     DevBuf<int32_t> queue, sup;
+    uint64_t seeds_since_clear = 0;
     // per-run
     int64_t run_nseeds = -1;
     DevBuf<int32_t> seeds_d, work_pos, out_cnt, status, nop_d;
@@ -594,11 +661,12 @@ struct arcte_hip_ctx {
         g.data = data.p;
         g.out_degree = out_degree.p;
         g.in_degree = in_degree.p;
+        g.edge_in_degree = edge_in_degree.p;
         return g;
     }
     size_t device_bytes() const
     {
-        return indptr.bytes() + indices.bytes() + data.bytes() + out_degree.bytes() + in_degree.bytes() + rs.bytes() +
+        return indptr.bytes() + indices.bytes() + data.bytes() + out_degree.bytes() + in_degree.bytes() + edge_in_degree.bytes() + state.bytes() + slot_epoch.bytes() +
                queue.bytes() + sup.bytes() + seeds_d.bytes() + work_pos.bytes() + out_cnt.bytes() + status.bytes() +
                nop_d.bytes() + eps_d.bytes() + out_off.bytes() + dst_off.bytes() + raw.bytes() + rows_final.bytes();
     }
@@ -608,10 +676,13 @@ namespace {
 
 int alloc_slots(arcte_hip_ctx *c, int64_t slots, uint32_t qcap)
 {
-    HIP_TRY(c->rs.alloc((size_t)slots * c->n));
+    HIP_TRY(c->state.alloc((size_t)slots * c->n));
+    HIP_TRY(c->slot_epoch.alloc((size_t)slots));
     HIP_TRY(c->sup.alloc((size_t)slots * c->n));
     HIP_TRY(c->queue.alloc((size_t)slots * qcap));
-    HIP_TRY(hipMemsetAsync(c->rs.p, 0, c->rs.bytes(), c->stream));
+    HIP_TRY(hipMemsetAsync(c->state.p, 0, c->state.bytes(), c->stream));
+    HIP_TRY(hipMemsetAsync(c->slot_epoch.p, 0, c->slot_epoch.bytes(), c->stream));
+    c->seeds_since_clear = 0;
     c->slots = slots;
     c->qcap = qcap;
     return 0;
@@ -627,7 +698,8 @@ int grow_queue(arcte_hip_ctx *c)
     slots = std::max<int64_t>(WAVES_PER_BLOCK, slots - slots % WAVES_PER_BLOCK);
     c->queue.release();
     if (slots != c->slots) {
-        c->rs.release();
+        c->state.release();
+        c->slot_epoch.release();
         c->sup.release();
         return alloc_slots(c, slots, nq);
     }
@@ -703,6 +775,7 @@ int arcte_hip_create(int device, int64_t n, int64_t nnz, const int64_t *indptr, 
         HIP_TRY(c->data.alloc(nnz));
         HIP_TRY(c->out_degree.alloc(n));
         HIP_TRY(c->in_degree.alloc(n));
+        HIP_TRY(c->edge_in_degree.alloc(nnz));
         HIP_TRY(hipMemcpyAsync(c->indptr.p, indptr, (n + 1) * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
         if (nnz) {
             HIP_TRY(hipMemcpyAsync(c->indices.p, indices, nnz * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
@@ -710,6 +783,11 @@ int arcte_hip_create(int device, int64_t n, int64_t nnz, const int64_t *indptr, 
         }
         HIP_TRY(hipMemcpyAsync(c->out_degree.p, out_degree, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipMemcpyAsync(c->in_degree.p, in_degree, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        if (nnz) {
+            hipLaunchKernelGGL(k_edge_in_degree, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, c->stream, c->indices.p,
+                               c->in_degree.p, c->edge_in_degree.p, nnz);
+            HIP_TRY(hipGetLastError());
+        }
         HIP_TRY(c->counters.alloc(8));
         int64_t slots = n_slots;
         if (slots <= 0) {
@@ -720,11 +798,11 @@ int arcte_hip_create(int device, int64_t n, int64_t nnz, const int64_t *indptr, 
             // keep the slot scratch within a fixed share of the device
             size_t free_b = 0, total_b = 0;
             HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-            size_t per_slot = (size_t)n * (sizeof(double2) + sizeof(int32_t)) + (size_t)next_pow2(std::max<int64_t>(n, 4096)) * 4;
-            while (slots > WAVES_PER_BLOCK && (size_t)slots * per_slot > free_b / 2) slots /= 2;
+            size_t per_slot = (size_t)n * (sizeof(Entry) + sizeof(int32_t)) + (size_t)default_queue_capacity(n) * 4;
+            while (slots > WAVES_PER_BLOCK && (size_t)slots * per_slot > free_b / 4 * 3) slots -= WAVES_PER_BLOCK * c->cus / 4;
         }
         slots = std::max<int64_t>(WAVES_PER_BLOCK, (slots + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK * WAVES_PER_BLOCK);
-        uint32_t qcap = next_pow2((uint64_t)(queue_capacity > 0 ? queue_capacity : std::max<int64_t>(n, 4096)));
+        uint32_t qcap = queue_capacity > 0 ? next_pow2((uint64_t)queue_capacity) : default_queue_capacity(n);
         if (qcap < (uint32_t)WAVE) qcap = WAVE;
         int r = alloc_slots(c, slots, qcap);
         if (r) return r;
@@ -747,7 +825,7 @@ int arcte_hip_destroy(arcte_hip_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     c->indptr.release(); c->indices.release(); c->data.release(); c->out_degree.release(); c->in_degree.release();
-    c->rs.release(); c->queue.release(); c->sup.release();
+    c->state.release(); c->slot_epoch.release(); c->edge_in_degree.release(); c->queue.release(); c->sup.release();
     c->seeds_d.release(); c->work_pos.release(); c->out_cnt.release(); c->status.release(); c->nop_d.release();
     c->eps_d.release(); c->out_off.release(); c->dst_off.release(); c->counters.release();
     c->raw.release(); c->rows_final.release();
@@ -807,6 +885,13 @@ int arcte_hip_run_seeds(arcte_hip_ctx *c, const int64_t *seeds, int64_t nseeds, 
     for (auto &m : c->ms) m = 0;
     int r = upload_seeds(c, seeds, nseeds);
     if (r) return r;
+    // epochs are 32-bit and advance by one per seed and slot: clear long before any slot can wrap
+    c->seeds_since_clear += (uint64_t)nseeds;
+    if (c->seeds_since_clear > (1ull << 31)) {
+        HIP_TRY(hipMemsetAsync(c->state.p, 0, c->state.bytes(), c->stream));
+        HIP_TRY(hipMemsetAsync(c->slot_epoch.p, 0, c->slot_epoch.bytes(), c->stream));
+        c->seeds_since_clear = (uint64_t)nseeds;
+    }
     HIP_TRY(c->out_cnt.alloc(nseeds));
     HIP_TRY(c->status.alloc(nseeds));
     HIP_TRY(c->nop_d.alloc(nseeds));
@@ -870,7 +955,8 @@ int arcte_hip_run_seeds(arcte_hip_ctx *c, const int64_t *seeds, int64_t nseeds, 
         P.seeds = c->seeds_d.p;
         P.eps = c->eps_d.p;
         P.one_minus_rho = 1 - rho;
-        P.rs = c->rs.p;
+        P.state = c->state.p;
+        P.slot_epoch = c->slot_epoch.p;
         P.queue = c->queue.p;
         P.sup = c->sup.p;
         P.qcap = c->qcap;
@@ -1084,7 +1170,8 @@ int arcte_hip_similarity_slice(arcte_hip_ctx *c, int64_t seed, double rho, doubl
             HIP_TRY(hipMemcpyAsync(sd.p, s, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
             HIP_TRY(hipMemcpyAsync(rd.p, r, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
             const int tb = 256;
-            hipLaunchKernelGGL(k_interleave, dim3((unsigned)((n + tb - 1) / tb)), dim3(tb), 0, c->stream, sd.p, rd.p, c->rs.p, n);
+            hipLaunchKernelGGL(k_state_from_dense, dim3((unsigned)((n + tb - 1) / tb)), dim3(tb), 0, c->stream, sd.p, rd.p,
+                               c->in_degree.p, c->state.p, c->slot_epoch.p, n);
             HIP_TRY(hipMemsetAsync(c->counters.p, 0, 8 * sizeof(unsigned long long), c->stream));
             PushParams P;
             P.g = c->graph();
@@ -1094,7 +1181,8 @@ int arcte_hip_similarity_slice(arcte_hip_ctx *c, int64_t seed, double rho, doubl
             P.seeds = seed_d.p;
             P.eps = eps1.p;
             P.one_minus_rho = 1 - rho;
-            P.rs = c->rs.p;
+            P.state = c->state.p;
+        P.slot_epoch = c->slot_epoch.p;
             P.queue = c->queue.p;
             P.sup = c->sup.p;
             P.qcap = c->qcap;
@@ -1113,21 +1201,19 @@ int arcte_hip_similarity_slice(arcte_hip_ctx *c, int64_t seed, double rho, doubl
             HIP_TRY(hipMemcpyAsync(h, small.p, sizeof(h), hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(hipStreamSynchronize(c->stream));
             if (h[1] == ST_RUNAWAY) {
-                HIP_TRY(hipMemsetAsync(c->rs.p, 0, n * sizeof(double2), c->stream));
-                HIP_TRY(hipStreamSynchronize(c->stream));
                 return fail(ARCTE_HIP_ECAPACITY, "push cap reached after " + std::to_string(h[2]) + " pushes");
             }
             if (h[1] == ST_QUEUE_OVERFLOW) {
-                // slot 0 must be clean again for later runs; then retry with a deeper ring
-                HIP_TRY(hipMemsetAsync(c->rs.p, 0, n * sizeof(double2), c->stream));
+                // the epoch has moved on, so slot 0 is clean again; retry with a deeper ring
                 r2 = grow_queue(c);
                 if (r2) return r2;
                 continue;
             }
-            hipLaunchKernelGGL(k_deinterleave, dim3((unsigned)((n + tb - 1) / tb)), dim3(tb), 0, c->stream, c->rs.p, sd.p, rd.p, n);
+            hipLaunchKernelGGL(k_state_to_dense, dim3((unsigned)((n + tb - 1) / tb)), dim3(tb), 0, c->stream, c->state.p,
+                               c->slot_epoch.p, sd.p, rd.p, n);
             HIP_TRY(hipMemcpyAsync(s, sd.p, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(hipMemcpyAsync(r, rd.p, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-            HIP_TRY(hipMemsetAsync(c->rs.p, 0, n * sizeof(double2), c->stream));   // slot 0 back to all-zero
+            // nothing to clean: the next seed on slot 0 runs in a new epoch
             HIP_TRY(hipStreamSynchronize(c->stream));
             if (nop) *nop = h[2];
             return 0;
