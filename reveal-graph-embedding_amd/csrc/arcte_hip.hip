@@ -253,7 +253,7 @@ struct PushParams {
     Entry *state;      // [slots][n]
     uint32_t *slot_epoch;   // [slots] last epoch used by the slot
     int32_t *queue;    // [slots][qcap]
-    int32_t *sup;      // [slots][n]   first-touch list
+    int32_t *sup;      // [slots][n]   candidate list (see cand_thr)
     uint32_t qcap;     // power of two
     int32_t max_pushes; // per-seed cap, see ST_RUNAWAY
     // outputs
@@ -316,7 +316,9 @@ __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
         epoch++;                           // every entry of the previous seed is stale from here on
 
         uint32_t head = 0, tail = 0;       // ring counters (wave-uniform)
-        int32_t nsup = 0;
+        int32_t nsup = 0;          // candidates
+        int32_t nfirst = 0;        // nodes with s != 0 (the support of the similarity slice)
+        double cand_thr = 0.0;
         int32_t npush = 0;
         unsigned long long nedges = 0;
         bool ok = true, runaway = false;
@@ -354,10 +356,15 @@ __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
                         store_lo(st + v, r_new, s_new);
                         if (!live) store_hi(st + v, dv, epoch);
                     }
-                    const bool first = act && !live;                         // the touched list grows
-                    const uint64_t mf = __ballot(first);
-                    if (first) sup[nsup + lane_below(mf)] = v;
-                    nsup += __popcll(mf);
+                    // Candidate list: every node whose s/in_degree has reached cand_thr, a lower bound of
+                    // the final selection threshold (s only grows, so each node crosses once).  It replaces
+                    // the full touched list: extraction only has to look at candidates.
+                    const double bar = cand_thr * dv;
+                    const bool cross = act && (s_new > 0.0 && s_new >= bar) && !(s_old > 0.0 && s_old >= bar);
+                    const uint64_t mc = __ballot(cross);
+                    if (cross) sup[nsup + lane_below(mc)] = v;
+                    nsup += __popcll(mc);
+                    nfirst += __popcll(__ballot(act && s_old == 0.0 && s_new != 0.0));   // support of s grows
                     const bool enq = act && (r_new / dv >= eps);             // similarity.py:194/214
                     const uint64_t me = __ballot(enq);
                     const uint32_t cnt = __popcll(me);
@@ -377,17 +384,29 @@ __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
         };
 
         // ---- similarity.py:176-192: s[seed] = r[seed] = 1, one unconditional push
+        const int64_t seed_b = g.indptr[seed], seed_e = g.indptr[seed + 1];
+        const double seed_d = g.in_degree[seed];
         if (lane == 0) {
-            if (MODE == 0) {
-                store_lo(st + seed, 1.0, 1.0);
-                store_hi(st + seed, g.in_degree[seed], epoch);
-            } else {
-                store_lo(st + seed, 1.0, 1.0);     // the host made every entry live (caller's s, r)
-            }
+            store_lo(st + seed, 1.0, 1.0);
+            if (MODE == 0) store_hi(st + seed, seed_d, epoch);   // MODE 1: the host made every entry live
             sup[0] = seed;
         }
         nsup = 1;
-        push(seed, 1.0, g.indptr[seed], g.indptr[seed + 1]);
+        nfirst = 1;
+        if (MODE == 0) {
+            // Lower bound of the selection threshold (arcte.py:358-360): the threshold is the minimum of
+            // s/in_degree over the closed neighbourhood at the END; s never decreases, so the minimum
+            // right after the first push (s[b] = c*w_b, s[seed] >= 1) bounds it from below.  Scaled down a
+            // hair so that the cheap product test s >= cand_thr*d admits everything the exact division does.
+            double lb = 1.0 / seed_d;
+            const double c0 = omr * 1.0;
+            for (int64_t k = seed_b + lane; k < seed_e; k += WAVE) {
+                const double x = (c0 * g.data[k]) / g.edge_in_degree[k];
+                lb = (x < lb) ? x : lb;
+            }
+            cand_thr = wave_min(lb) * (1.0 - 0x1p-40);
+        }
+        push(seed, 1.0, seed_b, seed_e);
 
         // ---- similarity.py:199-216: FIFO with duplicates.  Up to 64 queue entries are taken per
         //      batch; r/in_degree of all of them is tested in parallel and the first passing entry
@@ -427,7 +446,7 @@ __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
 
         // ---- arcte.py:352-376: degree-normalise, threshold = min over the closed neighbourhood,
         //      select everything at or above it, emit iff larger than the base community.
-        //      One pass over the touched list: selected nodes are compacted in place, then copied.
+        //      One pass over the candidate list: selected nodes are compacted in place, then copied.
         int32_t sta = ok ? ST_OK : (runaway ? ST_RUNAWAY : ST_QUEUE_OVERFLOW);
         int32_t emitted = 0, support = 0;
         unsigned long long off = 0;
@@ -450,19 +469,17 @@ __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
                 int32_t cnt = 0;
                 for (int32_t i0 = 0; i0 < nsup; i0 += WAVE) {
                     const int32_t i = i0 + lane;
-                    bool sel = false, nz = false;
+                    bool sel = false;
                     int32_t v = 0;
                     if (i < nsup) {
                         v = sup[i];
-                        const double sv = st[v].s;
-                        nz = sv != 0.0;                                   // csr_matrix(s) keeps non-zeros only
-                        sel = nz && (sv / st[v].d >= thr);
+                        sel = (st[v].s / st[v].d) >= thr;                 // arcte.py:363-367
                     }
                     const uint64_t ms = __ballot(sel);
                     if (sel) sup[cnt + lane_below(ms)] = v;               // in place: cnt <= i0
                     cnt += __popcll(ms);
-                    support += __popcll(__ballot(nz));
                 }
+                support = nfirst;
                 if ((int64_t)cnt > (se - sb) + 1) {                                   // arcte.py:370
                     if (lane == 0) off = atomicAdd(P.raw_cursor, (unsigned long long)cnt);
                     off = bcast_u64(off);
