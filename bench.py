@@ -177,6 +177,9 @@ def main():
     st = ctx.stats()
     tm = ctx.timing()
     _, total_rows = ctx.result_sizes()
+    t = time.perf_counter()
+    ctx.fetch()                      # D2H of the step's result: reported beside the metric, never inside it
+    fetch_ms = (time.perf_counter() - t) * 1e3
     if rank == 0:
         alg = algorithmic_bytes(st)
         kernel_ms = push_ms / max(args.steps, 1)
@@ -218,6 +221,8 @@ def main():
                 "per_seed": {k: st[k] / max(shard.size, 1) for k in ("pushes", "edges", "enqueues", "support")},
                 "reruns": st["reruns"],
                 "eps_kernel_ms": tm["eps_ms"], "compact_ms": tm["compact_ms"], "call_ms": tm["call_ms"],
+                "result_d2h_ms_rank0": fetch_ms,
+                "pcie_inclusive_seeds_per_s_rank0": shard.size / ((elapsed / max(args.steps, 1)) + fetch_ms * 1e-3),
             },
             "roofline": {
                 "bound": "hbm", "kernel": "k_arcte_seeds<0>",
