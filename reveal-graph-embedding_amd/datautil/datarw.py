@@ -1,0 +1,46 @@
+"""Mirror of the two I/O functions of reveal_graph_embedding/datautil/datarw.py the ARCTE entry point
+uses: the edge-list reader (reference datarw.py:54-120) and the triplet feature writer (:123-143)."""
+import numpy as np
+import scipy.sparse as spsp
+
+from reveal_graph_embedding_amd.common import get_file_row_generator
+
+
+def read_adjacency_matrix(file_path, separator, undirected):
+    """
+    Reads an edge list (`source<sep>target<sep>weight` per line, lines starting with '#' skipped) and
+    returns (adjacency_matrix as scipy COO float64, node_to_id).  Node ids are renumbered in first-seen
+    order, source before target (reference :87-92); node_to_id maps the new numbers back.  With
+    `undirected`, every non-loop edge also gets its reciprocal (:105-109).  Duplicate edges stay
+    duplicate COO entries (they are summed when the matrix is converted, as in the reference).
+    """
+    id_to_node = dict()
+    row, col, data = [], [], []
+    for file_row in get_file_row_generator(file_path, separator):
+        if file_row[0][0] == "#":
+            continue
+        source_node = id_to_node.setdefault(int(file_row[0]), len(id_to_node))
+        target_node = id_to_node.setdefault(int(file_row[1]), len(id_to_node))
+        edge_weight = float(file_row[2])
+        row.append(source_node)
+        col.append(target_node)
+        data.append(edge_weight)
+        if undirected and source_node != target_node:
+            row.append(target_node)
+            col.append(source_node)
+            data.append(edge_weight)
+    number_of_nodes = len(id_to_node)
+    node_to_id = dict(zip(id_to_node.values(), id_to_node.keys()))
+    adjacency_matrix = spsp.coo_matrix((np.array(data, dtype=np.float64),
+                                        (np.array(row, dtype=np.int64), np.array(col, dtype=np.int64))),
+                                       shape=(number_of_nodes, number_of_nodes))
+    return adjacency_matrix, node_to_id
+
+
+def write_features(file_path, features, separator, node_to_id):
+    """One line per stored entry, in COO-of-CSR order: `<original node id><sep><column><sep><int(value)>`."""
+    features = spsp.coo_matrix(features)
+    ids = np.array([node_to_id[i] for i in range(features.shape[0])], dtype=object) if features.shape[0] else []
+    with open(file_path, "w") as f:
+        f.writelines(str(ids[r]) + separator + str(c) + separator + str(int(v)) + "\n"
+                     for r, c, v in zip(features.row.tolist(), features.col.tolist(), features.data.tolist()))
