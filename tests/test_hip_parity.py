@@ -234,3 +234,43 @@ def test_config1_rmat_all_seeds_matches_reference_hash():
     h.update(f.indptr.astype(np.int64).tobytes())
     h.update(f.indices.astype(np.int64).tobytes())
     assert np.array_equal(np.frombuffer(h.digest(), dtype=np.uint8), z["sha256"])
+
+
+def test_full_size_1m_graph_properties_and_sampled_oracle_parity():
+    """BASELINE.json configs[2] at full size (R-MAT 1M nodes / 50M sampled edges): size-independent
+    properties on a seed shard plus exact agreement with the oracle on a random sample of it."""
+    adjacency = rmat_graph(1000000, 50000000, seed=0)
+    assert adjacency.nnz == 88123742
+    w, od, idg = get_natural_random_walk_matrix(adjacency)
+    from reveal_graph_embedding_amd.embedding.arcte.arcte import seed_nodes
+    seeds = seed_nodes(adjacency)
+    assert seeds.size == 651465
+    shard = seeds[5::64]                      # ~10k seeds spread over the whole degree range
+    deg = np.diff(w.indptr)
+    results = []
+    for slots in (0, 512):                    # result must not depend on how many seeds are in flight
+        with _native.Context(w.indptr, w.indices, w.data, od, idg, n_slots=slots) as ctx:
+            ctx.run_seeds(shard, 0.1, 1e-5)
+            results.append(ctx.fetch(want_nop=True) + (ctx.stats(),))
+    (colptr, rows, nop, st), (colptr2, rows2, nop2, st2) = results
+    assert np.array_equal(colptr, colptr2) and np.array_equal(nop, nop2)
+    assert [st[k] for k in ("pushes", "edges", "enqueues", "support")] == \
+           [st2[k] for k in ("pushes", "edges", "enqueues", "support")]
+    sizes = np.diff(colptr)
+    emitted = sizes > 0
+    assert np.all(sizes[emitted] > deg[shard][emitted] + 1)          # arcte.py:370
+    assert np.all(nop >= 1)
+    for k in np.flatnonzero(emitted)[::97]:
+        members = np.sort(rows[colptr[k]:colptr[k + 1]])
+        assert np.array_equal(members, np.sort(rows2[colptr2[k]:colptr2[k + 1]]))
+        assert np.unique(members).size == members.size
+        base = np.append(w.indices[w.indptr[shard[k]]:w.indptr[shard[k] + 1]], shard[k])
+        assert np.all(np.isin(base, members))                         # community contains N[seed]
+    rng = np.random.default_rng(7)
+    pick = np.sort(rng.choice(shard.size, size=1500, replace=False))
+    o_colptr, o_rows, _, o_nop, _ = oracle.worker(w, od, idg, shard[pick], 0.1, 1e-5,
+                                                  threads=oracle.lib().oracle_max_threads(), want_stats=True)
+    assert np.array_equal(o_nop, nop[pick])
+    assert np.array_equal(np.diff(o_colptr), sizes[pick])
+    for j, k in enumerate(pick):
+        assert np.array_equal(np.sort(rows[colptr[k]:colptr[k + 1]]), o_rows[o_colptr[j]:o_colptr[j + 1]])
