@@ -81,6 +81,20 @@ int arcte_hip_epsilon_effective(arcte_hip_ctx *ctx, const int64_t *seeds, int64_
 int arcte_hip_run_seeds(arcte_hip_ctx *ctx, const int64_t *seeds, int64_t nseeds,
                         double rho, double epsilon, int use_effective_epsilon);
 
+/*
+ * The same loop for the reference's PageRank-flavoured workers.  variant 0 = arcte_hip_run_seeds;
+ * variant 1 = arcte_with_pagerank_worker (embedding/arcte/arcte.py:166-276: pushes of
+ * eps_randomwalk/push.py:4-17 driven by similarity.py:11-63); variant 2 =
+ * arcte_with_lazy_pagerank_worker (arcte.py:53-163: push.py:20-38, similarity.py:66-146 with its
+ * self re-push loops; laziness_factor as at similarity.py:75, and `rho` is what the worker hands
+ * down, i.e. the caller applies lazy_rho of arcte.py:109).  Both guard the extraction with the
+ * intersection test of arcte.py:129-133: a seed whose closed neighbourhood is not inside the support
+ * (or that has a self-loop) emits nothing instead of failing.
+ */
+int arcte_hip_run_seeds_variant(arcte_hip_ctx *ctx, const int64_t *seeds, int64_t nseeds,
+                                double rho, double epsilon, int use_effective_epsilon,
+                                int variant, double laziness_factor);
+
 /* Sizes of the last run: number of seeds and total emitted (row, seed) pairs. */
 int arcte_hip_result_sizes(arcte_hip_ctx *ctx, int64_t *nseeds, int64_t *total_rows);
 
@@ -125,6 +139,13 @@ int arcte_hip_run_timing(arcte_hip_ctx *ctx, double ms[4]);
 int arcte_hip_similarity_slice(arcte_hip_ctx *ctx, int64_t seed, double rho, double epsilon,
                                double *s, double *r, int64_t *nop);
 
+/* fast_approximate_personalized_pagerank (similarity.py:11-63, variant 1) and
+ * lazy_approximate_personalized_pagerank (similarity.py:66-146, variant 2) with the same contract
+ * (only r[seed] is set to 1 there); variant 0 = arcte_hip_similarity_slice. */
+int arcte_hip_similarity_slice_variant(arcte_hip_ctx *ctx, int64_t seed, double rho, double epsilon,
+                                       int variant, double laziness_factor,
+                                       double *s, double *r, int64_t *nop);
+
 /*
  * cumulative_pagerank_difference_limit_push (eps_randomwalk/push.py:41-64): one push of
  * `push_node` over (w_i, a_i) on caller-owned dense s[n], r[n].  Context-free.
@@ -132,6 +153,11 @@ int arcte_hip_similarity_slice(arcte_hip_ctx *ctx, int64_t seed, double rho, dou
 int arcte_hip_push(int device, int64_t n, double *s, double *r,
                    const double *w_i, const int32_t *a_i, int64_t deg,
                    int64_t push_node, double rho);
+
+/* pagerank_limit_push (push.py:4-17, variant 1) and pagerank_lazy_push (push.py:20-38, variant 2). */
+int arcte_hip_push_variant(int device, int64_t n, double *s, double *r,
+                           const double *w_i, const int32_t *a_i, int64_t deg,
+                           int64_t push_node, double rho, int variant, double laziness_factor);
 
 /* Properties of the context: info[0] slots, [1] queue capacity, [2] device bytes held,
  * [3] compute units, [4] wavefronts per workgroup. */

@@ -16,6 +16,9 @@
  *   eps_randomwalk/similarity.py:149-222  -> oracle_similarity
  *   embedding/arcte/arcte.py:26-50        -> oracle_epsilon_effective
  *   embedding/arcte/arcte.py:279-388      -> oracle_worker (per-seed body 337-376)
+ *   eps_randomwalk/push.py:4-17, 20-38    -> oracle_push_variant (PageRank / lazy PageRank pushes)
+ *   eps_randomwalk/similarity.py:11-63, 66-146 -> oracle_similarity_variant
+ *   embedding/arcte/arcte.py:53-276       -> oracle_worker_variant (intersection guard :129-133, lazy_rho :109)
  *
  * Arithmetic is IEEE binary64 with the reference's operation order; build with
  * -ffp-contract=off so `c*w` then `+` never fuses into an FMA (push.py:62-64).
@@ -130,15 +133,42 @@ static inline void deposit(double *s, double *r, int32_t v, double p, int32_t *t
     if (touched && s_old == 0.0 && s_new != 0.0) touched[(*ntouched)++] = v;
 }
 
-static int64_t similarity_core(const int64_t *indptr, const int32_t *indices, const double *data,
-                               const double *in_degree, int64_t seed, double rho, double epsilon,
-                               double *s, double *r, fifo_t *q, int32_t *touched, int64_t *ntouched,
-                               oracle_stats_t *st)
+/* variant 0: cumulative PageRank difference (push.py:41-64, similarity.py:149-222)
+ * variant 1: PageRank limit push (push.py:4-17, similarity.py:11-63)
+ * variant 2: lazy PageRank push (push.py:20-38, similarity.py:66-146) with its self re-push loops */
+static void push_any(int variant, double lazy, int64_t b, int64_t e, const int32_t *indices, const double *data,
+                     double *s, double *r, int64_t u, double rho, int32_t *touched, int64_t *ntouched)
+{
+    if (g_trace) { if (g_trace_len < g_trace_cap) g_trace[g_trace_len] = (int32_t)u; g_trace_len++; }
+    if (variant == 0) {
+        double commute = (1 - rho) * r[u];               /* push.py:56 */
+        r[u] = 0.0;                                      /* push.py:59 */
+        for (int64_t k = b; k < e; k++)                  /* push.py:62-64 */
+            deposit(s, r, indices[k], commute * data[k], touched, ntouched);
+    } else {
+        double A = rho * r[u];                           /* push.py:10 / :29 */
+        double B, C;
+        if (variant == 1) { B = (1 - rho) * r[u]; C = 0.0; }                 /* push.py:11, :15 */
+        else { B = (1 - rho) * (1 - lazy) * r[u]; C = (1 - rho) * lazy * (r[u]); }   /* push.py:30-31 */
+        double s_old = s[u];
+        s[u] += A;                                       /* push.py:14 / :34 */
+        if (touched && s_old == 0.0 && s[u] != 0.0) touched[(*ntouched)++] = (int32_t)u;
+        r[u] = C;                                        /* push.py:15 / :35 */
+        for (int64_t k = b; k < e; k++) r[indices[k]] += B * data[k];        /* push.py:17 / :38 */
+    }
+}
+
+static int64_t similarity_core_v(int variant, double lazy, const int64_t *indptr, const int32_t *indices,
+                                 const double *data, const double *in_degree, int64_t seed, double rho,
+                                 double epsilon, double *s, double *r, fifo_t *q, int32_t *touched,
+                                 int64_t *ntouched, oracle_stats_t *st, int32_t *rtouched, int64_t *nrtouched)
 {
     int64_t nop = 0;
-    if (touched && s[seed] == 0.0) touched[(*ntouched)++] = (int32_t)seed;
-    s[seed] = 1.0;                                           /* similarity.py:176 */
-    r[seed] = 1.0;                                           /* :177 */
+    if (variant == 0) {
+        if (touched && s[seed] == 0.0) touched[(*ntouched)++] = (int32_t)seed;
+        s[seed] = 1.0;                                       /* similarity.py:176 */
+    }
+    r[seed] = 1.0;                                           /* similarity.py:177 / :26 / :85 */
     q->head = q->tail = 0;
     int64_t u = seed;
     int first = 1;
@@ -147,17 +177,14 @@ static int64_t similarity_core(const int64_t *indptr, const int32_t *indices, co
             if (q->head == q->tail) break;                   /* :199 */
             u = q->buf[q->head++];                           /* :200 */
         }
-        /* :186 unconditional first push; :204 threshold at pop time afterwards */
+        /* unconditional first push; threshold at pop time afterwards (:204, :51, :124) */
         if (first || r[u] / in_degree[u] >= epsilon) {
-            double commute = (1 - rho) * r[u];               /* push.py:56 */
-            r[u] = 0.0;                                      /* push.py:59 */
-            if (g_trace) { if (g_trace_len < g_trace_cap) g_trace[g_trace_len] = (int32_t)u; g_trace_len++; }
             int64_t b = indptr[u], e = indptr[u + 1];
-            for (int64_t k = b; k < e; k++)                  /* push.py:62-64 */
-                deposit(s, r, indices[k], commute * data[k], touched, ntouched);
+            push_any(variant, lazy, b, e, indices, data, s, r, u, rho, touched, ntouched);
             nop++;
-            for (int64_t k = b; k < e; k++) {                /* similarity.py:194-196 / :214-216, CSR order */
+            for (int64_t k = b; k < e; k++) {                /* enqueue in CSR order (:194-196, :43-45, :105-107) */
                 int32_t v = indices[k];
+                if (rtouched) rtouched[(*nrtouched)++] = v;
                 if (r[v] / in_degree[v] >= epsilon) {
                     if (fifo_push(q, v)) return -1;
                     if (st) st->enqueues++;
@@ -165,9 +192,27 @@ static int64_t similarity_core(const int64_t *indptr, const int32_t *indices, co
             }
             if (st) { st->pushes++; st->edges += e - b; }
         }
+        if (variant == 2) {
+            /* similarity.py:108-116 and :136-144: re-push the same node while it stays above the
+             * threshold; no enqueue after these pushes */
+            while (r[u] / in_degree[u] >= epsilon) {
+                push_any(variant, lazy, indptr[u], indptr[u + 1], indices, data, s, r, u, rho, touched, ntouched);
+                nop++;
+                if (st) { st->pushes++; st->edges += indptr[u + 1] - indptr[u]; }
+            }
+        }
         first = 0;
     }
     return nop;
+}
+
+static int64_t similarity_core(const int64_t *indptr, const int32_t *indices, const double *data,
+                               const double *in_degree, int64_t seed, double rho, double epsilon,
+                               double *s, double *r, fifo_t *q, int32_t *touched, int64_t *ntouched,
+                               oracle_stats_t *st)
+{
+    return similarity_core_v(0, 0.0, indptr, indices, data, in_degree, seed, rho, epsilon, s, r, q, touched,
+                             ntouched, st, 0, 0);
 }
 
 /* similarity.py:149-222 on caller-owned dense s, r (mutated in place); returns nop. */
@@ -188,17 +233,31 @@ static int cmp_i32(const void *a, const void *b)
     return (x > y) - (x < y);
 }
 
+typedef struct { int32_t *buf; int64_t cap, len; } ivec_t;
+
+static int ivec_reserve(ivec_t *v, int64_t extra)
+{
+    if (v->len + extra <= v->cap) return 0;
+    int64_t ncap = v->cap ? v->cap : 4096;
+    while (ncap < v->len + extra) ncap *= 2;
+    int32_t *nb = (int32_t *)realloc(v->buf, (size_t)ncap * sizeof(int32_t));
+    if (!nb) return -1;
+    v->buf = nb;
+    v->cap = ncap;
+    return 0;
+}
+
 /*
- * arcte.py:337-376 for one seed on zeroed s, r.  Writes the emitted community
- * (ascending node ids) to rows_out (capacity n) and returns its size, 0 when the
- * reference emits nothing (:370), -1 on allocation failure, -2 when a member of
- * the closed neighbourhood is missing from the support (the reference would
- * mis-index at :359-360).  s, r are returned to all-zero.
+ * arcte.py:337-376 (variant 0) / :101-155 (variant 2) / :223-268 (variant 1) for one seed on zeroed s, r.
+ * Writes the emitted community (ascending node ids) to rows_out (capacity n) and returns its size, 0 when
+ * the reference emits nothing, -1 on allocation failure, -2 (variant 0 only) when a member of the closed
+ * neighbourhood is missing from the support (the reference would mis-index at :359-360; the PageRank
+ * flavours guard against it with the intersection test :129-133 and skip the seed).  s, r return to zero.
  */
-static int64_t seed_body(int64_t n, const int64_t *indptr, const int32_t *indices, const double *data,
+static int64_t seed_body(int variant, int64_t n, const int64_t *indptr, const int32_t *indices, const double *data,
                          const double *out_degree, const double *in_degree, int64_t seed,
                          double rho, double epsilon, double *s, double *r, fifo_t *q,
-                         int32_t *touched, double *nbr_deg, int32_t *rows_out,
+                         int32_t *touched, ivec_t *rt, double *nbr_deg, int32_t *rows_out,
                          double *eps_out, int64_t *nop_out, oracle_stats_t *st)
 {
     (void)n;
@@ -206,29 +265,80 @@ static int64_t seed_body(int64_t n, const int64_t *indptr, const int32_t *indice
     for (int64_t k = 0; k < deg; k++) nbr_deg[k] = out_degree[indices[b + k]];            /* :340 */
     double eps_eff = oracle_epsilon_effective(epsilon, out_degree[seed], nbr_deg, deg);
     if (eps_out) *eps_out = eps_eff;
+    double rho_used = rho, lazy = 0.0;
+    if (variant == 2) { rho_used = (rho * (0.5)) / (1 - (0.5 * rho)); lazy = 0.5; }        /* :109, default laziness */
     int64_t nt = 0;
-    int64_t nop = similarity_core(indptr, indices, data, in_degree, seed, rho, eps_eff, s, r, q,
-                                  touched, &nt, st);                                      /* :342-350 */
+    int64_t nop;
+    if (variant == 0) {
+        nop = similarity_core_v(0, 0.0, indptr, indices, data, in_degree, seed, rho, eps_eff, s, r, q, touched, &nt, st, 0, 0);
+    } else {
+        /* Same driver as similarity_core_v, inlined because the PageRank flavours deposit to r only: the
+         * places r was touched are remembered (one entry per traversed edge, grown between pushes) so that
+         * the per-seed "r[:] = 0" costs what was touched, not n. */
+        rt->len = 0;
+        if (ivec_reserve(rt, 1)) return -1;
+        nop = 0;
+        r[seed] = 1.0;
+        rt->buf[rt->len++] = (int32_t)seed;
+        q->head = q->tail = 0;
+        int64_t u = seed;
+        int first = 1;
+        int fail = 0;
+        for (;;) {
+            if (!first) {
+                if (q->head == q->tail) break;
+                u = q->buf[q->head++];
+            }
+            if (first || r[u] / in_degree[u] >= eps_eff) {
+                int64_t ub = indptr[u], ue = indptr[u + 1];
+                if (ivec_reserve(rt, ue - ub)) { fail = 1; break; }
+                push_any(variant, lazy, ub, ue, indices, data, s, r, u, rho_used, touched, &nt);
+                nop++;
+                for (int64_t k = ub; k < ue; k++) {
+                    int32_t v = indices[k];
+                    rt->buf[rt->len++] = v;
+                    if (r[v] / in_degree[v] >= eps_eff) {
+                        if (fifo_push(q, v)) { fail = 1; break; }
+                        if (st) st->enqueues++;
+                    }
+                }
+                if (fail) break;
+                if (st) { st->pushes++; st->edges += ue - ub; }
+            }
+            if (variant == 2) {
+                while (r[u] / in_degree[u] >= eps_eff) {                                   /* similarity.py:108,136 */
+                    push_any(variant, lazy, indptr[u], indptr[u + 1], indices, data, s, r, u, rho_used, touched, &nt);
+                    nop++;
+                    if (st) { st->pushes++; st->edges += indptr[u + 1] - indptr[u]; }
+                }
+            }
+            first = 0;
+        }
+        if (fail) nop = -1;
+    }
     if (nop_out) *nop_out = nop;
     int64_t result = 0;
     if (nop < 0) result = -1;
     else {
         /* :352-360  s_norm = s / in_degree on the support; threshold = min over N[seed] + seed */
         double thr = INFINITY;
-        int missing = 0;
+        int missing = 0, selfloop = 0;
         for (int64_t k = b; k <= e; k++) {
             int32_t v = (k < e) ? indices[k] : (int32_t)seed;
+            if (k < e && v == seed) selfloop = 1;
             if (s[v] == 0.0) { missing = 1; break; }
             double x = s[v] / in_degree[v];
             if (x < thr) thr = x;
         }
-        if (missing) result = -2;
+        /* PageRank flavours: np.intersect1d returns unique ids, base_community counts a self-loop twice,
+         * so a seed with a self-loop never passes the guard (arcte.py:129-133) */
+        if (variant != 0 && (missing || selfloop)) result = 0;
+        else if (missing) result = -2;
         else {
-            /* :363-367  count of support entries with s_norm >= thr (searchsorted side='left') */
             int64_t k_sel = 0;
             for (int64_t t = 0; t < nt; t++) {
                 int32_t v = touched[t];
-                if (s[v] / in_degree[v] >= thr) rows_out[k_sel++] = v;
+                if (s[v] / in_degree[v] >= thr) rows_out[k_sel++] = v;                    /* :363-367 */
             }
             if (k_sel > deg + 1) {                                                        /* :370 */
                 qsort(rows_out, (size_t)k_sel, sizeof(int32_t), cmp_i32);
@@ -238,21 +348,21 @@ static int64_t seed_body(int64_t n, const int64_t *indptr, const int32_t *indice
         if (st) st->support += nt;
     }
     for (int64_t t = 0; t < nt; t++) { s[touched[t]] = 0.0; r[touched[t]] = 0.0; }         /* :337-338 */
-    /* r can be non-zero only where s is (every deposit hits both; the seed is in the list) */
+    if (variant != 0) for (int64_t t = 0; t < rt->len; t++) r[rt->buf[t]] = 0.0;
     return result;
 }
 
 /*
- * arcte.py:279-388 over a list of seeds.  Output is column-compressed: for seed k,
- * rows[colptr[k] .. colptr[k+1]) are the members of its local community (empty when
- * not emitted).  rows is malloc'ed here and handed back through *rows_io (caller frees
- * with oracle_free).  eps_eff/nop/stats4 may be NULL.  stats4 = {pushes, edges,
- * enqueues, support} summed over the seeds.  threads <= 1 runs single-threaded.
+ * arcte.py:279-388 (variant 0), :166-276 (variant 1), :53-163 (variant 2) over a list of seeds.  Output is
+ * column-compressed: for seed k, rows[colptr[k] .. colptr[k+1]) are the members of its local community
+ * (empty when not emitted).  rows is malloc'ed here and handed back through *rows_io (caller frees with
+ * oracle_free).  eps_eff/nop/stats4 may be NULL.  stats4 = {pushes, edges, enqueues, support} summed over
+ * the seeds.  threads <= 1 runs single-threaded.
  */
-int oracle_worker(int64_t n, const int64_t *indptr, const int32_t *indices, const double *data,
-                  const double *out_degree, const double *in_degree,
-                  const int64_t *seeds, int64_t nseeds, double rho, double epsilon, int threads,
-                  int64_t *colptr, int32_t **rows_io, double *eps_eff, int64_t *nop, int64_t *stats4)
+int oracle_worker_variant(int variant, int64_t n, const int64_t *indptr, const int32_t *indices, const double *data,
+                          const double *out_degree, const double *in_degree,
+                          const int64_t *seeds, int64_t nseeds, double rho, double epsilon, int threads,
+                          int64_t *colptr, int32_t **rows_io, double *eps_eff, int64_t *nop, int64_t *stats4)
 {
     int64_t maxdeg = 0;
     for (int64_t i = 0; i < n; i++) {
@@ -275,6 +385,7 @@ int oracle_worker(int64_t n, const int64_t *indptr, const int32_t *indices, cons
         int32_t *rows_tmp = (int32_t *)malloc((size_t)(n + 1) * sizeof(int32_t));
         double *nbr_deg = (double *)malloc((size_t)(maxdeg + 1) * sizeof(double));
         fifo_t q = {0, 0, 0, 0};
+        ivec_t rt = {0, 0, 0};
         oracle_stats_t st = {0, 0, 0, 0};
         int ok = s && r && touched && rows_tmp && nbr_deg;
 #ifdef _OPENMP
@@ -282,8 +393,8 @@ int oracle_worker(int64_t n, const int64_t *indptr, const int32_t *indices, cons
 #endif
         for (int64_t k = 0; k < nseeds; k++) {
             if (!ok) continue;
-            int64_t c = seed_body(n, indptr, indices, data, out_degree, in_degree, seeds[k], rho, epsilon,
-                                  s, r, &q, touched, nbr_deg, rows_tmp,
+            int64_t c = seed_body(variant, n, indptr, indices, data, out_degree, in_degree, seeds[k], rho, epsilon,
+                                  s, r, &q, touched, &rt, nbr_deg, rows_tmp,
                                   eps_eff ? eps_eff + k : 0, nop ? nop + k : 0, &st);
             if (c < 0) {
 #ifdef _OPENMP
@@ -307,7 +418,7 @@ int oracle_worker(int64_t n, const int64_t *indptr, const int32_t *indices, cons
             total.pushes += st.pushes; total.edges += st.edges;
             total.enqueues += st.enqueues; total.support += st.support;
         }
-        free(s); free(r); free(touched); free(rows_tmp); free(nbr_deg); free(q.buf);
+        free(s); free(r); free(touched); free(rows_tmp); free(nbr_deg); free(q.buf); free(rt.buf);
     }
     colptr[0] = 0;
     for (int64_t k = 0; k < nseeds; k++) colptr[k + 1] = colptr[k] + counts[k];
@@ -322,6 +433,35 @@ int oracle_worker(int64_t n, const int64_t *indptr, const int32_t *indices, cons
     *rows_io = rows;
     if (stats4) { stats4[0] = total.pushes; stats4[1] = total.edges; stats4[2] = total.enqueues; stats4[3] = total.support; }
     return status;
+}
+
+int oracle_worker(int64_t n, const int64_t *indptr, const int32_t *indices, const double *data,
+                  const double *out_degree, const double *in_degree,
+                  const int64_t *seeds, int64_t nseeds, double rho, double epsilon, int threads,
+                  int64_t *colptr, int32_t **rows_io, double *eps_eff, int64_t *nop, int64_t *stats4)
+{
+    return oracle_worker_variant(0, n, indptr, indices, data, out_degree, in_degree, seeds, nseeds, rho, epsilon,
+                                 threads, colptr, rows_io, eps_eff, nop, stats4);
+}
+
+/* similarity.py:11-63 (variant 1) / :66-146 (variant 2) / :149-222 (variant 0) on caller-owned dense s, r. */
+int64_t oracle_similarity_variant(int variant, double lazy, int64_t n, const int64_t *indptr, const int32_t *indices,
+                                  const double *data, const double *in_degree, int64_t seed, double rho,
+                                  double epsilon, double *s, double *r)
+{
+    (void)n;
+    fifo_t q = {0, 0, 0, 0};
+    int64_t nop = similarity_core_v(variant, lazy, indptr, indices, data, in_degree, seed, rho, epsilon, s, r, &q,
+                                    0, 0, 0, 0, 0);
+    free(q.buf);
+    return nop;
+}
+
+/* push.py:4-17 (variant 1), :20-38 (variant 2), :41-64 (variant 0): one push on caller-owned s, r. */
+void oracle_push_variant(int variant, double lazy, double *s, double *r, const double *w_i, const int32_t *a_i,
+                         int64_t deg, int64_t push_node, double rho)
+{
+    push_any(variant, lazy, 0, deg, a_i, w_i, s, r, push_node, rho, 0, 0);
 }
 
 /* Pushed node ids of one seed run with its effective epsilon (arcte.py:340-350); returns the push

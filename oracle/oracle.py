@@ -55,6 +55,12 @@ def lib():
         l.oracle_push_trace.restype = C.c_int64
         l.oracle_push_trace.argtypes = [C.c_int64, _i64p, _i32p, _f64p, _f64p, _f64p, C.c_int64, C.c_double, C.c_double,
                                         _i32p, C.c_int64]
+        l.oracle_worker_variant.restype = C.c_int
+        l.oracle_worker_variant.argtypes = [C.c_int] + l.oracle_worker.argtypes
+        l.oracle_similarity_variant.restype = C.c_int64
+        l.oracle_similarity_variant.argtypes = [C.c_int, C.c_double] + l.oracle_similarity.argtypes
+        l.oracle_push_variant.restype = None
+        l.oracle_push_variant.argtypes = [C.c_int, C.c_double] + l.oracle_push.argtypes
         l.oracle_free.restype = None
         l.oracle_free.argtypes = [C.c_void_p]
         l.oracle_max_threads.restype = C.c_int
@@ -94,7 +100,25 @@ def similarity(w, in_degree, seed, rho, epsilon, s, r):
                                    int(seed), float(rho), float(epsilon), s, r)
 
 
-def worker(w, out_degree, in_degree, seeds, rho, epsilon, threads=1, want_stats=False):
+ARCTE, PAGERANK, LAZY_PAGERANK = 0, 1, 2
+
+
+def push_variant(variant, s, r, w_i, a_i, push_node, rho, lazy=0.5):
+    """push.py:4-17 (PAGERANK), :20-38 (LAZY_PAGERANK), :41-64 (ARCTE), in place on s, r."""
+    w_i = np.ascontiguousarray(w_i, dtype=np.float64)
+    a_i = np.ascontiguousarray(a_i, dtype=np.int32)
+    lib().oracle_push_variant(int(variant), float(lazy), s, r, w_i, a_i, a_i.size, int(push_node), float(rho))
+
+
+def similarity_variant(variant, w, in_degree, seed, rho, epsilon, s, r, lazy=0.5):
+    """similarity.py:11-63 (PAGERANK), :66-146 (LAZY_PAGERANK), :149-222 (ARCTE); returns nop."""
+    indptr, indices, data = _csr_arrays(w)
+    return lib().oracle_similarity_variant(int(variant), float(lazy), w.shape[0], indptr, indices, data,
+                                           np.ascontiguousarray(in_degree, dtype=np.float64),
+                                           int(seed), float(rho), float(epsilon), s, r)
+
+
+def worker(w, out_degree, in_degree, seeds, rho, epsilon, threads=1, want_stats=False, variant=0):
     """arcte.py:279-388.  Returns (colptr[int64, nseeds+1], rows[int32]) and, with
     want_stats, also (eps_eff, nop, stats4 = [pushes, edges, enqueues, support])."""
     indptr, indices, data = _csr_arrays(w)
@@ -105,7 +129,7 @@ def worker(w, out_degree, in_degree, seeds, rho, epsilon, threads=1, want_stats=
     eps_eff = np.zeros(seeds.size, dtype=np.float64)
     nop = np.zeros(seeds.size, dtype=np.int64)
     stats = np.zeros(4, dtype=np.int64)
-    rc = lib().oracle_worker(n, indptr, indices, data,
+    rc = lib().oracle_worker_variant(int(variant), n, indptr, indices, data,
                              np.ascontiguousarray(out_degree, dtype=np.float64),
                              np.ascontiguousarray(in_degree, dtype=np.float64),
                              seeds, seeds.size, float(rho), float(epsilon), int(threads),
@@ -132,11 +156,11 @@ def push_trace(w, out_degree, in_degree, seed, rho, epsilon, cap=1 << 16):
     return buf[:min(n, cap)].copy()
 
 
-def worker_matrix(w, out_degree, in_degree, seeds, rho, epsilon, threads=1):
+def worker_matrix(w, out_degree, in_degree, seeds, rho, epsilon, threads=1, variant=0):
     """arcte_worker's return value: n x n CSR of ones, column = seed id (arcte.py:379-388)."""
     n = w.shape[0]
     seeds = np.asarray(seeds, dtype=np.int64)
-    colptr, rows = worker(w, out_degree, in_degree, seeds, rho, epsilon, threads)
+    colptr, rows = worker(w, out_degree, in_degree, seeds, rho, epsilon, threads, variant=variant)
     cols = np.repeat(seeds, np.diff(colptr))
     m = sparse.coo_matrix((np.ones(rows.size, dtype=np.float64), (rows.astype(np.int64), cols)), shape=(n, n))
     return sparse.csr_matrix(m)
@@ -168,14 +192,14 @@ def seed_list(adjacency_matrix):
     return nodes[cnt[nodes] > 1]
 
 
-def arcte(adjacency_matrix, rho, epsilon, number_of_threads=1):
+def arcte(adjacency_matrix, rho, epsilon, number_of_threads=1, variant=0):
     """arcte.py:591-688.  Chunking over processes (:650-673) only partitions the
     seed list and sums disjoint columns, so the thread count cannot change the result."""
     adjacency_matrix = sparse.csr_matrix(adjacency_matrix)
     n = adjacency_matrix.shape[0]
     w, out_degree, in_degree = get_natural_random_walk_matrix(adjacency_matrix)
     seeds = seed_list(adjacency_matrix)
-    local = worker_matrix(w, out_degree, in_degree, seeds, rho, epsilon, threads=number_of_threads)
+    local = worker_matrix(w, out_degree, in_degree, seeds, rho, epsilon, threads=number_of_threads, variant=variant)
     identity = sparse.csr_matrix(sparse.eye(n, n, dtype=np.float64))               # :676
     ones = adjacency_matrix.copy()
     ones.data = np.ones_like(ones.data)                                             # :677-678

@@ -26,6 +26,8 @@ SIGNATURES = {
     "arcte_hip_destroy": (C.c_int, [C.c_void_p]),
     "arcte_hip_epsilon_effective": (C.c_int, [C.c_void_p, _i64p, C.c_int64, C.c_double, _f64p]),
     "arcte_hip_run_seeds": (C.c_int, [C.c_void_p, _i64p, C.c_int64, C.c_double, C.c_double, C.c_int]),
+    "arcte_hip_run_seeds_variant": (C.c_int, [C.c_void_p, _i64p, C.c_int64, C.c_double, C.c_double, C.c_int, C.c_int,
+                                              C.c_double]),
     "arcte_hip_result_sizes": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "arcte_hip_fetch_result": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "arcte_hip_result_device_rows": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
@@ -34,9 +36,16 @@ SIGNATURES = {
     "arcte_hip_run_timing": (C.c_int, [C.c_void_p, _f64p]),
     "arcte_hip_similarity_slice": (C.c_int, [C.c_void_p, C.c_int64, C.c_double, C.c_double, _f64p, _f64p,
                                              C.POINTER(C.c_int64)]),
+    "arcte_hip_similarity_slice_variant": (C.c_int, [C.c_void_p, C.c_int64, C.c_double, C.c_double, C.c_int, C.c_double,
+                                                     _f64p, _f64p, C.POINTER(C.c_int64)]),
+    "arcte_hip_push_variant": (C.c_int, [C.c_int, C.c_int64, _f64p, _f64p, _f64p, _i32p, C.c_int64, C.c_int64, C.c_double,
+                                         C.c_int, C.c_double]),
     "arcte_hip_push": (C.c_int, [C.c_int, C.c_int64, _f64p, _f64p, _f64p, _i32p, C.c_int64, C.c_int64, C.c_double]),
     "arcte_hip_info": (C.c_int, [C.c_void_p, _i64p]),
 }
+
+# push flavours (include/arcte_hip.h: `variant`)
+ARCTE, PAGERANK, LAZY_PAGERANK = 0, 1, 2
 
 _lib = None
 _lock = threading.Lock()
@@ -120,10 +129,11 @@ class Context:
         _check(lib().arcte_hip_epsilon_effective(self._h, seeds, seeds.size, float(epsilon), out))
         return out
 
-    def run_seeds(self, seeds, rho, epsilon, use_effective_epsilon=True):
+    def run_seeds(self, seeds, rho, epsilon, use_effective_epsilon=True, variant=ARCTE, laziness_factor=0.5):
         seeds = np.ascontiguousarray(seeds, dtype=np.int64)
-        _check(lib().arcte_hip_run_seeds(self._h, seeds, seeds.size, float(rho), float(epsilon),
-                                         1 if use_effective_epsilon else 0))
+        _check(lib().arcte_hip_run_seeds_variant(self._h, seeds, seeds.size, float(rho), float(epsilon),
+                                                 1 if use_effective_epsilon else 0, int(variant),
+                                                 float(laziness_factor)))
 
     def result_sizes(self):
         ns, tot = C.c_int64(0), C.c_int64(0)
@@ -178,19 +188,21 @@ class Context:
         return dict(slots=int(i[0]), queue_capacity=int(i[1]), device_bytes=int(i[2]), compute_units=int(i[3]),
                     waves_per_workgroup=int(i[4]))
 
-    def similarity_slice(self, seed, rho, epsilon, s, r):
+    def similarity_slice(self, seed, rho, epsilon, s, r, variant=ARCTE, laziness_factor=0.5):
         if s.dtype != np.float64 or r.dtype != np.float64 or not s.flags.c_contiguous or not r.flags.c_contiguous:
             raise TypeError("s and r must be C-contiguous float64 arrays (they are updated in place)")
         if s.size != self.n or r.size != self.n:
             raise ValueError("s and r must have one entry per node")
         nop = C.c_int64(0)
-        _check(lib().arcte_hip_similarity_slice(self._h, int(seed), float(rho), float(epsilon), s, r, C.byref(nop)))
+        _check(lib().arcte_hip_similarity_slice_variant(self._h, int(seed), float(rho), float(epsilon), int(variant),
+                                                        float(laziness_factor), s, r, C.byref(nop)))
         return nop.value
 
 
-def single_push(s, r, w_i, a_i, push_node, rho, device=0):
+def single_push(s, r, w_i, a_i, push_node, rho, device=0, variant=ARCTE, laziness_factor=0.5):
     if s.dtype != np.float64 or r.dtype != np.float64 or not s.flags.c_contiguous or not r.flags.c_contiguous:
         raise TypeError("s and r must be C-contiguous float64 arrays (they are updated in place)")
     w_i = np.ascontiguousarray(w_i, dtype=np.float64)
     a_i = np.ascontiguousarray(a_i, dtype=np.int32)
-    _check(lib().arcte_hip_push(int(device), s.size, s, r, w_i, a_i, a_i.size, int(push_node), float(rho)))
+    _check(lib().arcte_hip_push_variant(int(device), s.size, s, r, w_i, a_i, a_i.size, int(push_node), float(rho),
+                                        int(variant), float(laziness_factor)))

@@ -249,6 +249,8 @@ struct PushParams {
     const int32_t *seeds;
     const double *eps;
     double one_minus_rho;
+    double rho;        // PageRank flavours: s[u] += rho*r[u]
+    double lazy;       // lazy flavour: laziness factor
     // per-slot scratch
     Entry *state;      // [slots][n]
     uint32_t *slot_epoch;   // [slots] last epoch used by the slot
@@ -269,7 +271,10 @@ struct PushParams {
 
 // MODE 0: full arcte_worker body (extract).  MODE 1: similarity slice only on the dense vectors the
 // host placed in slot 0 (k_state_from_dense), left there for k_state_to_dense.
-template <int MODE>
+// VAR 0: cumulative PageRank difference (push.py:41-64, similarity.py:149-222) -- ARCTE proper.
+// VAR 1: PageRank limit push (push.py:4-17, similarity.py:11-63).
+// VAR 2: lazy PageRank push (push.py:20-38, similarity.py:66-146) with its self re-push loops.
+template <int MODE, int VAR>
 __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
 {
     const int lane = threadIdx.x & 63;
@@ -325,9 +330,29 @@ __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
 
         // ---- one push of node u (push.py:41-64) followed by the ordered enqueue of
         //      similarity.py:194-196 / :214-216.  `ru` is r[u] at pop time.
-        auto push = [&](int32_t u, double ru, int64_t rb, int64_t re) {
-            const double c = omr * ru;                       // push.py:56
-            if (lane == 0) st[u].r = 0.0;                    // push.py:59
+        auto push = [&](int32_t u, double ru, int64_t rb, int64_t re, bool do_enqueue) {
+            double c;            // what every neighbour receives per unit of transition weight
+            double r_self;       // r[u] right after the push bookkeeping (what a self-loop lane adds to)
+            if (VAR == 0) {
+                c = omr * ru;                                    // push.py:56
+                r_self = 0.0;
+                if (lane == 0) st[u].r = 0.0;                    // push.py:59
+            } else {
+                const double A = P.rho * ru;                     // push.py:10 / :29
+                if (VAR == 1) { c = omr * ru; r_self = 0.0; }                                  // push.py:11,15
+                else { c = omr * (1 - P.lazy) * ru; r_self = omr * P.lazy * (ru); }            // push.py:30-31
+                bool grew = false;
+                if (lane == 0) {
+                    const double s_old = st[u].s;                // u is live: it was deposited to, or is the seed
+                    const double s_new = s_old + A;              // push.py:14 / :34
+                    store_lo(st + u, r_self, s_new);             // push.py:15 / :35
+                    grew = s_old == 0.0 && s_new != 0.0;
+                    if (grew) sup[nsup] = u;                     // s is non-zero exactly at pushed nodes
+                }
+                const int g1 = __popcll(__ballot(grew));
+                nsup += g1;
+                nfirst += g1;
+            }
             for (int64_t base = rb; base < re; base += 2 * WAVE) {
                 const int64_t k0 = base + lane, k1 = k0 + WAVE;
                 const bool a0 = k0 < re, a1 = k1 < re;
@@ -347,24 +372,27 @@ __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
                     const double dv = t ? d1 : d0;
                     const EntryLo lo = t ? l1 : l0;
                     const bool live = (t ? h1.epoch : h0.epoch) == epoch;
-                    const double p = c * w;                                  // push.py:62
-                    const double r_old = (live && v != u) ? lo.r : 0.0;      // self-loop sees r[u] = 0
+                    const double p = c * w;                                  // push.py:62 / :17 / :38
+                    const double r_old = live ? ((v != u) ? lo.r : r_self) : 0.0;   // a self-loop sees r[u] as just set
                     const double s_old = live ? lo.s : 0.0;
                     const double r_new = r_old + p;                          // push.py:64
-                    const double s_new = s_old + p;                          // push.py:63
+                    const double s_new = (VAR == 0) ? s_old + p : s_old;     // push.py:63 (ARCTE only)
                     if (act) {
                         store_lo(st + v, r_new, s_new);
                         if (!live) store_hi(st + v, dv, epoch);
                     }
-                    // Candidate list: every node whose s/in_degree has reached cand_thr, a lower bound of
-                    // the final selection threshold (s only grows, so each node crosses once).  It replaces
-                    // the full touched list: extraction only has to look at candidates.
-                    const double bar = cand_thr * dv;
-                    const bool cross = act && (s_new > 0.0 && s_new >= bar) && !(s_old > 0.0 && s_old >= bar);
-                    const uint64_t mc = __ballot(cross);
-                    if (cross) sup[nsup + lane_below(mc)] = v;
-                    nsup += __popcll(mc);
-                    nfirst += __popcll(__ballot(act && s_old == 0.0 && s_new != 0.0));   // support of s grows
+                    if (VAR == 0) {
+                        // Candidate list: every node whose s/in_degree has reached cand_thr, a lower bound of
+                        // the final selection threshold (s only grows, so each node crosses once).  It replaces
+                        // the full touched list: extraction only has to look at candidates.
+                        const double bar = cand_thr * dv;
+                        const bool cross = act && (s_new > 0.0 && s_new >= bar) && !(s_old > 0.0 && s_old >= bar);
+                        const uint64_t mc = __ballot(cross);
+                        if (cross) sup[nsup + lane_below(mc)] = v;
+                        nsup += __popcll(mc);
+                        nfirst += __popcll(__ballot(act && s_old == 0.0 && s_new != 0.0));   // support of s grows
+                    }
+                    if (!do_enqueue) continue;
                     const bool enq = act && (r_new / dv >= eps);             // similarity.py:194/214
                     const uint64_t me = __ballot(enq);
                     const uint32_t cnt = __popcll(me);
@@ -387,13 +415,15 @@ __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
         const int64_t seed_b = g.indptr[seed], seed_e = g.indptr[seed + 1];
         const double seed_d = g.in_degree[seed];
         if (lane == 0) {
-            store_lo(st + seed, 1.0, 1.0);
+            if (VAR == 0) store_lo(st + seed, 1.0, 1.0);         // similarity.py:176-177
+            else if (MODE == 0) store_lo(st + seed, 1.0, 0.0);   // similarity.py:26 / :85: only r[seed] = 1
+            else st[seed].r = 1.0;                                //   (MODE 1: the caller's s[seed] stays)
             if (MODE == 0) store_hi(st + seed, seed_d, epoch);   // MODE 1: the host made every entry live
-            sup[0] = seed;
+            if (VAR == 0) sup[0] = seed;
         }
-        nsup = 1;
-        nfirst = 1;
-        if (MODE == 0) {
+        nsup = (VAR == 0) ? 1 : 0;
+        nfirst = (VAR == 0) ? 1 : 0;
+        if (MODE == 0 && VAR == 0) {
             // Lower bound of the selection threshold (arcte.py:358-360): the threshold is the minimum of
             // s/in_degree over the closed neighbourhood at the END; s never decreases, so the minimum
             // right after the first push (s[b] = c*w_b, s[seed] >= 1) bounds it from below.  Scaled down a
@@ -406,7 +436,16 @@ __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
             }
             cand_thr = wave_min(lb) * (1.0 - 0x1p-40);
         }
-        push(seed, 1.0, seed_b, seed_e);
+        // (PageRank flavours: s is non-zero only at pushed nodes; the candidate list is the pushed nodes)
+        push(seed, 1.0, seed_b, seed_e, true);
+        if (VAR == 2) {
+            // similarity.py:108-116: re-push the seed while it stays above the threshold, no enqueue
+            while (ok) {
+                const double ru2 = st[seed].r;
+                if (!(ru2 / seed_d >= eps)) break;
+                push(seed, ru2, seed_b, seed_e, false);
+            }
+        }
 
         // ---- similarity.py:199-216: FIFO with duplicates.  Up to 64 queue entries are taken per
         //      batch; r/in_degree of all of them is tested in parallel and the first passing entry
@@ -438,7 +477,16 @@ __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
                 const int64_t rb = shfl_i64(rb_l, i);
                 const int64_t re = shfl_i64(re_l, i);
                 consumed = i + 1;
-                push(u, ru, rb, re);
+                push(u, ru, rb, re, true);
+                if (VAR == 2) {
+                    // similarity.py:136-144: re-push the same node while it stays above the threshold
+                    const double du = shfl_f64(d_l, i);
+                    while (ok) {
+                        const double ru2 = st[u].r;
+                        if (!(ru2 / du >= eps)) break;
+                        push(u, ru2, rb, re, false);
+                    }
+                }
                 if (!ok) break;
                 if (valid && lane >= consumed) r_l = st[u_l].r;
             }
@@ -453,9 +501,10 @@ __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
         if (MODE == 0 && ok) {
             const int64_t sb = g.indptr[seed], se = g.indptr[seed + 1];
             double thr = st[seed].s / st[seed].d;
-            bool miss = false;
+            bool miss = st[seed].s == 0.0, selfloop = false;
             for (int64_t k = sb + lane; k < se; k += WAVE) {
                 const int32_t v = g.indices[k];
+                selfloop |= (v == seed);
                 const EntryLo lo = load_lo(st + v);
                 const EntryHi hi = load_hi(st + v);
                 const double sv = (hi.epoch == epoch) ? lo.s : 0.0;
@@ -464,8 +513,13 @@ __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
                 thr = (x < thr) ? x : thr;
             }
             thr = wave_min(thr);
-            if (__ballot(miss) != 0) sta = ST_MISSING_BASE;
-            else {
+            const bool missing = __ballot(miss) != 0;
+            if (VAR == 0 && missing) sta = ST_MISSING_BASE;
+            else if (VAR != 0 && (missing || __ballot(selfloop) != 0)) {
+                // arcte.py:129-133: the PageRank flavours skip a seed whose closed neighbourhood is not inside
+                // the support; intersect1d de-duplicates, so a seed with a self-loop never passes the guard
+                support = nfirst;
+            } else {
                 int32_t cnt = 0;
                 for (int32_t i0 = 0; i0 < nsup; i0 += WAVE) {
                     const int32_t i = i0 + lane;
@@ -555,14 +609,22 @@ __global__ void k_edge_in_degree(const int32_t *indices, const double *in_degree
     if (k < nnz) out[k] = in_degree[indices[k]];
 }
 
-// push.py:41-64 on dense device vectors, one workgroup
+// push.py:41-64 (variant 0), :4-17 (variant 1), :20-38 (variant 2) on dense device vectors, one workgroup
 __global__ __launch_bounds__(BLOCK) void k_single_push(double *s, double *r, const double *w_i, const int32_t *a_i,
-                                                       int64_t deg, int64_t push_node, double one_minus_rho)
+                                                       int64_t deg, int64_t push_node, double rho, double one_minus_rho,
+                                                       int variant, double lazy)
 {
     __shared__ double commute;
     if (threadIdx.x == 0) {
-        commute = one_minus_rho * r[push_node];
-        r[push_node] = 0.0;
+        const double ru = r[push_node];
+        if (variant == 0) {
+            commute = one_minus_rho * ru;
+            r[push_node] = 0.0;
+        } else {
+            s[push_node] += rho * ru;
+            if (variant == 1) { commute = one_minus_rho * ru; r[push_node] = 0.0; }
+            else { commute = one_minus_rho * (1 - lazy) * ru; r[push_node] = one_minus_rho * lazy * (ru); }
+        }
     }
     __syncthreads();
     __threadfence_block();
@@ -570,7 +632,7 @@ __global__ __launch_bounds__(BLOCK) void k_single_push(double *s, double *r, con
     for (int64_t k = threadIdx.x; k < deg; k += BLOCK) {
         const int32_t v = a_i[k];
         const double p = c * w_i[k];
-        s[v] += p;
+        if (variant == 0) s[v] += p;
         r[v] += p;
     }
 }
@@ -725,24 +787,32 @@ int grow_queue(arcte_hip_ctx *c)
     return 0;
 }
 
-template <int MODE>
-int launch_seeds(arcte_hip_ctx *c, const PushParams &P, int64_t nwork)
+template <int MODE, int VAR>
+int launch_seeds_v(arcte_hip_ctx *c, const PushParams &P, int64_t nwork)
 {
     int64_t waves = std::min<int64_t>(c->slots, std::max<int64_t>(nwork, 1));
     int blocks = (int)((waves + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
     // MODE 1 works on the dense vectors the host placed in slot 0: exactly one wavefront may run
     const int threads = (MODE == 1) ? WAVE : BLOCK;
     if (MODE == 1) blocks = 1;
-    hipLaunchKernelGGL(k_arcte_seeds<MODE>, dim3(blocks), dim3(threads), 0, c->stream, P);
+    hipLaunchKernelGGL((k_arcte_seeds<MODE, VAR>), dim3(blocks), dim3(threads), 0, c->stream, P);
     HIP_TRY(hipGetLastError());
     return 0;
+}
+
+template <int MODE>
+int launch_seeds(arcte_hip_ctx *c, const PushParams &P, int64_t nwork, int variant)
+{
+    if (variant == 1) return launch_seeds_v<MODE, 1>(c, P, nwork);
+    if (variant == 2) return launch_seeds_v<MODE, 2>(c, P, nwork);
+    return launch_seeds_v<MODE, 0>(c, P, nwork);
 }
 
 }  // namespace
 
 extern "C" {
 
-int arcte_hip_abi_version(void) { return 1; }
+int arcte_hip_abi_version(void) { return 2; }
 
 const char *arcte_hip_last_error(void) { return g_err.c_str(); }
 
@@ -809,7 +879,7 @@ int arcte_hip_create(int device, int64_t n, int64_t nnz, const int64_t *indptr, 
         int64_t slots = n_slots;
         if (slots <= 0) {
             int per_cu = 0;
-            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_arcte_seeds<0>, BLOCK, 0));
+            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (k_arcte_seeds<0, 0>), BLOCK, 0));
             per_cu = std::max(1, std::min(per_cu, 8));
             slots = (int64_t)per_cu * c->cus * WAVES_PER_BLOCK;
             // keep the slot scratch within a fixed share of the device
@@ -889,10 +959,11 @@ int arcte_hip_epsilon_effective(arcte_hip_ctx *c, const int64_t *seeds, int64_t 
     return 0;
 }
 
-int arcte_hip_run_seeds(arcte_hip_ctx *c, const int64_t *seeds, int64_t nseeds, double rho, double epsilon,
-                        int use_effective_epsilon)
+static int run_seeds_impl(arcte_hip_ctx *c, const int64_t *seeds, int64_t nseeds, double rho, double epsilon,
+                          int use_effective_epsilon, int variant, double lazy)
 {
     if (!c || nseeds < 0 || (nseeds && !seeds)) return fail(ARCTE_HIP_EINVAL, "bad argument");
+    if (variant < 0 || variant > 2) return fail(ARCTE_HIP_EINVAL, "variant must be 0 (ARCTE), 1 (PageRank) or 2 (lazy PageRank)");
     if (nseeds >= ((int64_t)1 << 31)) return fail(ARCTE_HIP_EINVAL, "too many seeds for one call");
     HIP_TRY(hipSetDevice(c->device));
     auto t0 = std::chrono::steady_clock::now();
@@ -972,6 +1043,8 @@ int arcte_hip_run_seeds(arcte_hip_ctx *c, const int64_t *seeds, int64_t nseeds, 
         P.seeds = c->seeds_d.p;
         P.eps = c->eps_d.p;
         P.one_minus_rho = 1 - rho;
+        P.rho = rho;
+        P.lazy = lazy;
         P.state = c->state.p;
         P.slot_epoch = c->slot_epoch.p;
         P.queue = c->queue.p;
@@ -987,7 +1060,7 @@ int arcte_hip_run_seeds(arcte_hip_ctx *c, const int64_t *seeds, int64_t nseeds, 
         P.nop = c->nop_d.p;
         P.stats = c->counters.p + 2;
         HIP_TRY(hipEventRecord(c->ev[2], c->stream));
-        r = launch_seeds<0>(c, P, nwork);
+        r = launch_seeds<0>(c, P, nwork, variant);
         if (r) return r;
         HIP_TRY(hipEventRecord(c->ev[3], c->stream));
         launches++;
@@ -1097,6 +1170,18 @@ int arcte_hip_run_seeds(arcte_hip_ctx *c, const int64_t *seeds, int64_t nseeds, 
     return 0;
 }
 
+int arcte_hip_run_seeds(arcte_hip_ctx *c, const int64_t *seeds, int64_t nseeds, double rho, double epsilon,
+                        int use_effective_epsilon)
+{
+    return run_seeds_impl(c, seeds, nseeds, rho, epsilon, use_effective_epsilon, 0, 0.0);
+}
+
+int arcte_hip_run_seeds_variant(arcte_hip_ctx *c, const int64_t *seeds, int64_t nseeds, double rho, double epsilon,
+                                int use_effective_epsilon, int variant, double laziness_factor)
+{
+    return run_seeds_impl(c, seeds, nseeds, rho, epsilon, use_effective_epsilon, variant, laziness_factor);
+}
+
 int arcte_hip_result_sizes(arcte_hip_ctx *c, int64_t *nseeds, int64_t *total_rows)
 {
     if (!c) return fail(ARCTE_HIP_EINVAL, "ctx is NULL");
@@ -1161,10 +1246,11 @@ int arcte_hip_run_timing(arcte_hip_ctx *c, double ms[4])
     return 0;
 }
 
-int arcte_hip_similarity_slice(arcte_hip_ctx *c, int64_t seed, double rho, double epsilon, double *s, double *r,
-                               int64_t *nop)
+static int similarity_slice_impl(arcte_hip_ctx *c, int64_t seed, double rho, double epsilon, int variant, double lazy,
+                                 double *s, double *r, int64_t *nop)
 {
     if (!c || !s || !r) return fail(ARCTE_HIP_EINVAL, "bad argument");
+    if (variant < 0 || variant > 2) return fail(ARCTE_HIP_EINVAL, "variant must be 0 (ARCTE), 1 (PageRank) or 2 (lazy PageRank)");
     if (seed < 0 || seed >= c->n) return fail(ARCTE_HIP_EINVAL, "seed id out of range");
     HIP_TRY(hipSetDevice(c->device));
     c->run_nseeds = -1;
@@ -1198,6 +1284,8 @@ int arcte_hip_similarity_slice(arcte_hip_ctx *c, int64_t seed, double rho, doubl
             P.seeds = seed_d.p;
             P.eps = eps1.p;
             P.one_minus_rho = 1 - rho;
+            P.rho = rho;
+            P.lazy = lazy;
             P.state = c->state.p;
         P.slot_epoch = c->slot_epoch.p;
             P.queue = c->queue.p;
@@ -1212,7 +1300,7 @@ int arcte_hip_similarity_slice(arcte_hip_ctx *c, int64_t seed, double rho, doubl
             P.status = small.p + 1;
             P.nop = small.p + 2;
             P.stats = c->counters.p + 2;
-            int r2 = launch_seeds<1>(c, P, 1);
+            int r2 = launch_seeds<1>(c, P, 1, variant);
             if (r2) return r2;
             int32_t h[3];
             HIP_TRY(hipMemcpyAsync(h, small.p, sizeof(h), hipMemcpyDeviceToHost, c->stream));
@@ -1240,9 +1328,22 @@ int arcte_hip_similarity_slice(arcte_hip_ctx *c, int64_t seed, double rho, doubl
     return rc;
 }
 
-int arcte_hip_push(int device, int64_t n, double *s, double *r, const double *w_i, const int32_t *a_i, int64_t deg,
-                   int64_t push_node, double rho)
+int arcte_hip_similarity_slice(arcte_hip_ctx *c, int64_t seed, double rho, double epsilon, double *s, double *r,
+                               int64_t *nop)
 {
+    return similarity_slice_impl(c, seed, rho, epsilon, 0, 0.0, s, r, nop);
+}
+
+int arcte_hip_similarity_slice_variant(arcte_hip_ctx *c, int64_t seed, double rho, double epsilon, int variant,
+                                       double laziness_factor, double *s, double *r, int64_t *nop)
+{
+    return similarity_slice_impl(c, seed, rho, epsilon, variant, laziness_factor, s, r, nop);
+}
+
+static int push_impl(int device, int64_t n, double *s, double *r, const double *w_i, const int32_t *a_i, int64_t deg,
+                     int64_t push_node, double rho, int variant, double lazy)
+{
+    if (variant < 0 || variant > 2) return fail(ARCTE_HIP_EINVAL, "variant must be 0 (ARCTE), 1 (PageRank) or 2 (lazy PageRank)");
     if (!s || !r || n <= 0 || deg < 0 || (deg && (!w_i || !a_i))) return fail(ARCTE_HIP_EINVAL, "bad argument");
     if (push_node < 0 || push_node >= n) return fail(ARCTE_HIP_EINVAL, "push_node out of range");
     for (int64_t k = 0; k < deg; k++)
@@ -1261,7 +1362,8 @@ int arcte_hip_push(int device, int64_t n, double *s, double *r, const double *w_
             HIP_TRY(hipMemcpy(wd.p, w_i, deg * sizeof(double), hipMemcpyHostToDevice));
             HIP_TRY(hipMemcpy(ad.p, a_i, deg * sizeof(int32_t), hipMemcpyHostToDevice));
         }
-        hipLaunchKernelGGL(k_single_push, dim3(1), dim3(BLOCK), 0, 0, sd.p, rd.p, wd.p, ad.p, deg, push_node, 1 - rho);
+        hipLaunchKernelGGL(k_single_push, dim3(1), dim3(BLOCK), 0, 0, sd.p, rd.p, wd.p, ad.p, deg, push_node, rho, 1 - rho,
+                           variant, lazy);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipDeviceSynchronize());
         HIP_TRY(hipMemcpy(s, sd.p, n * sizeof(double), hipMemcpyDeviceToHost));
@@ -1270,6 +1372,18 @@ int arcte_hip_push(int device, int64_t n, double *s, double *r, const double *w_
     }();
     sd.release(); rd.release(); wd.release(); ad.release();
     return rc;
+}
+
+int arcte_hip_push(int device, int64_t n, double *s, double *r, const double *w_i, const int32_t *a_i, int64_t deg,
+                   int64_t push_node, double rho)
+{
+    return push_impl(device, n, s, r, w_i, a_i, deg, push_node, rho, 0, 0.0);
+}
+
+int arcte_hip_push_variant(int device, int64_t n, double *s, double *r, const double *w_i, const int32_t *a_i,
+                           int64_t deg, int64_t push_node, double rho, int variant, double laziness_factor)
+{
+    return push_impl(device, n, s, r, w_i, a_i, deg, push_node, rho, variant, laziness_factor);
 }
 
 int arcte_hip_info(arcte_hip_ctx *c, int64_t info[5])

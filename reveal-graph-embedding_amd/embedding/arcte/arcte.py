@@ -48,18 +48,41 @@ def _seed_matrix(n, seeds, colptr, rows):
     return sparse.csr_matrix(features)
 
 
+def _worker(variant, iterate_nodes, indices_c, indptr_c, data_c, out_degree, in_degree, rho, epsilon, device):
+    iterate_nodes = np.asarray(iterate_nodes, dtype=np.int64).reshape(-1)
+    number_of_nodes = out_degree.size
+    laziness_factor = 0.5
+    if variant == _native.LAZY_PAGERANK:
+        rho = (rho*(0.5))/(1-(0.5*rho))          # lazy_rho, reference arcte.py:109
+    with _native.Context(indptr_c, indices_c, data_c, out_degree, in_degree, device=device) as ctx:
+        ctx.run_seeds(iterate_nodes, rho, epsilon, use_effective_epsilon=True, variant=variant,
+                      laziness_factor=laziness_factor)
+        colptr, rows = ctx.fetch()
+    return _seed_matrix(number_of_nodes, iterate_nodes, colptr, rows)
+
+
 def arcte_worker(iterate_nodes, indices_c, indptr_c, data_c, out_degree, in_degree, rho, epsilon, device=0):
     """
     Local community features of the seeds in `iterate_nodes` (reference arcte.py:279-388): n x n CSR of
     ones whose column j holds the local community of seed j.  Takes the flat CSR arrays of the
     random-walk matrix exactly as the reference's pool workers do; `device` picks the GPU.
     """
-    iterate_nodes = np.asarray(iterate_nodes, dtype=np.int64).reshape(-1)
-    number_of_nodes = out_degree.size
-    with _native.Context(indptr_c, indices_c, data_c, out_degree, in_degree, device=device) as ctx:
-        ctx.run_seeds(iterate_nodes, rho, epsilon, use_effective_epsilon=True)
-        colptr, rows = ctx.fetch()
-    return _seed_matrix(number_of_nodes, iterate_nodes, colptr, rows)
+    return _worker(_native.ARCTE, iterate_nodes, indices_c, indptr_c, data_c, out_degree, in_degree, rho, epsilon,
+                   device)
+
+
+def arcte_with_pagerank_worker(iterate_nodes, indices_c, indptr_c, data_c, out_degree, in_degree, rho, epsilon,
+                               device=0):
+    """The PageRank-push flavour of arcte_worker (reference arcte.py:166-276)."""
+    return _worker(_native.PAGERANK, iterate_nodes, indices_c, indptr_c, data_c, out_degree, in_degree, rho,
+                   epsilon, device)
+
+
+def arcte_with_lazy_pagerank_worker(iterate_nodes, indices_c, indptr_c, data_c, out_degree, in_degree, rho, epsilon,
+                                    device=0):
+    """The lazy-PageRank-push flavour of arcte_worker (reference arcte.py:53-163; lazy_rho of :109, laziness 0.5)."""
+    return _worker(_native.LAZY_PAGERANK, iterate_nodes, indices_c, indptr_c, data_c, out_degree, in_degree, rho,
+                   epsilon, device)
 
 
 def seed_nodes(adjacency_matrix):
@@ -71,6 +94,16 @@ def seed_nodes(adjacency_matrix):
     iterate_nodes = np.where(edge_count_vector > 1)[0]
     order = np.argsort(-edge_count_vector[iterate_nodes], kind="stable")
     return iterate_nodes[order]
+
+
+def arcte_with_pagerank(adjacency_matrix, rho, epsilon, number_of_threads=None):
+    """arcte() with PageRank pushes (reference arcte.py:490-588): same driver, different worker."""
+    return _arcte_driver(adjacency_matrix, rho, epsilon, number_of_threads, arcte_with_pagerank_worker)
+
+
+def arcte_with_lazy_pagerank(adjacency_matrix, rho, epsilon, number_of_threads=None):
+    """arcte() with lazy PageRank pushes (reference arcte.py:391-489): same driver, different worker."""
+    return _arcte_driver(adjacency_matrix, rho, epsilon, number_of_threads, arcte_with_lazy_pagerank_worker)
 
 
 def arcte(adjacency_matrix, rho, epsilon, number_of_threads=None):
@@ -88,6 +121,10 @@ def arcte(adjacency_matrix, rho, epsilon, number_of_threads=None):
     Outputs: - X in R^(nx2n): CSR; columns [0, n) are the base communities I + pattern(A),
                columns [n, 2n) the ARCTE local communities.
     """
+    return _arcte_driver(adjacency_matrix, rho, epsilon, number_of_threads, arcte_worker)
+
+
+def _arcte_driver(adjacency_matrix, rho, epsilon, number_of_threads, worker):
     adjacency_matrix = sparse.csr_matrix(adjacency_matrix)
     number_of_nodes = adjacency_matrix.shape[0]
 
@@ -101,8 +138,8 @@ def arcte(adjacency_matrix, rho, epsilon, number_of_threads=None):
     iterate_nodes = seed_nodes(adjacency_matrix)
 
     if n_gpus == 1 or iterate_nodes.size < 2:
-        local_features = arcte_worker(iterate_nodes, rw_transition.indices, rw_transition.indptr, rw_transition.data,
-                                      out_degree, in_degree, rho, epsilon)
+        local_features = worker(iterate_nodes, rw_transition.indices, rw_transition.indptr, rw_transition.data,
+                                out_degree, in_degree, rho, epsilon)
     else:
         chunks = [c for c in parallel_chunks(iterate_nodes, n_gpus)]
         results = [None] * n_gpus
@@ -111,8 +148,8 @@ def arcte(adjacency_matrix, rho, epsilon, number_of_threads=None):
         def work(k):
             try:
                 if chunks[k] is not None:
-                    results[k] = arcte_worker(chunks[k], rw_transition.indices, rw_transition.indptr,
-                                              rw_transition.data, out_degree, in_degree, rho, epsilon, device=k)
+                    results[k] = worker(chunks[k], rw_transition.indices, rw_transition.indptr,
+                                        rw_transition.data, out_degree, in_degree, rho, epsilon, device=k)
             except BaseException as e:  # surfaced below; the reference drops worker errors silently
                 errors.append(e)
 

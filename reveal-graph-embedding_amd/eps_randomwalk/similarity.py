@@ -1,4 +1,5 @@
-"""Mirror of reveal_graph_embedding/eps_randomwalk/similarity.py (ARCTE variant, reference lines 149-222)."""
+"""Mirror of reveal_graph_embedding/eps_randomwalk/similarity.py (reference lines 11-222): the three
+eps-truncated propagations, same signatures, run on the GPU."""
 import collections
 
 import numpy as np
@@ -47,6 +48,29 @@ def fast_approximate_cumulative_pagerank_difference(s, r, w_i, a_i, out_degree, 
     """
     ctx = _context_for(w_i, a_i, out_degree, in_degree)
     return ctx.similarity_slice(seed_node, rho, epsilon, s, r)
+
+
+def fast_approximate_personalized_pagerank(s, r, w_i, a_i, out_degree, in_degree, seed_node, rho=0.2,
+                                           epsilon=0.00001):
+    """
+    Calculates the approximate personalized PageRank starting from a seed node without self-loops
+    (reference similarity.py:11-63).  Only r[seed_node] is set to 1; s and r are updated in place; returns
+    the number of push operations.
+    """
+    ctx = _context_for(w_i, a_i, out_degree, in_degree)
+    return ctx.similarity_slice(seed_node, rho, epsilon, s, r, variant=_native.PAGERANK)
+
+
+def lazy_approximate_personalized_pagerank(s, r, w_i, a_i, out_degree, in_degree, seed_node, rho=0.2,
+                                           epsilon=0.00001, laziness_factor=0.5):
+    """
+    Calculates the approximate personalized PageRank starting from a seed node with self-loops
+    (reference similarity.py:66-146; Andersen, Chung, Lang 2006), including the reference's re-push loops
+    (:108-116, :136-144).  Same contract as above.
+    """
+    ctx = _context_for(w_i, a_i, out_degree, in_degree)
+    return ctx.similarity_slice(seed_node, rho, epsilon, s, r, variant=_native.LAZY_PAGERANK,
+                                laziness_factor=laziness_factor)
 
 
 # name used by the task description; the reference's own name is the one above

@@ -286,8 +286,80 @@ def run_config1_hash():
     print("config-1 R-MAT: feature nnz", f.nnz, "sha256", h.hexdigest())
 
 
+def run_pagerank_variants(name, adjacency, rho, epsilon):
+    """The PageRank-flavoured siblings (similarity.py:11-146, push.py:4-38, arcte.py:53-276, 391-588),
+    stored as <name>_pagerank.npz next to the main fixture (same sampled seeds)."""
+    from reveal_graph_embedding.eps_randomwalk.similarity import (fast_approximate_personalized_pagerank,
+                                                                  lazy_approximate_personalized_pagerank)
+    from reveal_graph_embedding.eps_randomwalk.push import pagerank_limit_push, pagerank_lazy_push
+    from reveal_graph_embedding.embedding.arcte.arcte import (arcte_with_pagerank, arcte_with_lazy_pagerank,
+                                                              arcte_with_pagerank_worker,
+                                                              arcte_with_lazy_pagerank_worker)
+    main = np.load(os.path.join(HERE, name + ".npz"))
+    seeds = main["seeds"]
+    eps_eff = main["eps_eff"]
+    adjacency = sparse.csr_matrix(adjacency, dtype=np.float64)
+    n = adjacency.shape[0]
+    w, out_degree, in_degree = get_natural_random_walk_matrix(adjacency, make_shared=False)
+    adjacent_nodes = np.ndarray(n, dtype=np.ndarray)
+    base_transitions = np.ndarray(n, dtype=np.ndarray)
+    for i in range(n):
+        adjacent_nodes[i] = w.indices[w.indptr[i]: w.indptr[i + 1]]
+        base_transitions[i] = w.data[w.indptr[i]: w.indptr[i + 1]]
+    out = {"rho": np.float64(rho), "epsilon": np.float64(epsilon), "seeds": seeds}
+    lazy_rho = (rho * (0.5)) / (1 - (0.5 * rho))
+    out["lazy_rho"] = np.float64(lazy_rho)
+    for tag in ("pr", "lazy"):
+        nops, svecs, rvecs = [], [], []
+        for k, sd in enumerate(seeds):
+            s = np.zeros(n)
+            r = np.zeros(n)
+            if tag == "pr":
+                nop = fast_approximate_personalized_pagerank(s, r, base_transitions[:], adjacent_nodes[:], out_degree,
+                                                             in_degree, sd, rho, eps_eff[k])
+            else:
+                nop = lazy_approximate_personalized_pagerank(s, r, base_transitions[:], adjacent_nodes[:], out_degree,
+                                                             in_degree, sd, lazy_rho, eps_eff[k])
+            nops.append(nop)
+            svecs.append(s)
+            rvecs.append(r)
+        out[tag + "_nop"] = np.array(nops, dtype=np.int64)
+        out[tag + "_s_ptr"], out[tag + "_s_idx"], out[tag + "_s_val"] = pack_sparse_vectors(svecs)
+        out[tag + "_r_ptr"], out[tag + "_r_idx"], out[tag + "_r_val"] = pack_sparse_vectors(rvecs)
+        worker = arcte_with_pagerank_worker if tag == "pr" else arcte_with_lazy_pagerank_worker
+        wf = canon(worker(seeds, w.indices, w.indptr, w.data, out_degree, in_degree, rho, epsilon))
+        out[tag + "_worker_indptr"] = wf.indptr.astype(np.int64)
+        out[tag + "_worker_indices"] = wf.indices.astype(np.int32)
+        driver = arcte_with_pagerank if tag == "pr" else arcte_with_lazy_pagerank
+        f = canon(driver(adjacency.copy(), rho, epsilon, 1))
+        out[tag + "_feat_indptr"] = f.indptr.astype(np.int64)
+        out[tag + "_feat_indices"] = f.indices.astype(np.int32)
+        out[tag + "_feat_data"] = f.data.astype(np.float64)
+        # one isolated push from a non-trivial state
+        rng2 = np.random.default_rng(77)
+        s0, r0 = rng2.random(n), rng2.random(n)
+        u = int(seeds[0])
+        s1, r1 = s0.copy(), r0.copy()
+        if tag == "pr":
+            pagerank_limit_push(s1, r1, base_transitions[u], adjacent_nodes[u], u, rho)
+        else:
+            pagerank_lazy_push(s1, r1, base_transitions[u], adjacent_nodes[u], u, rho, 0.5)
+        out[tag + "_push_s_in"], out[tag + "_push_r_in"] = s0, r0
+        out[tag + "_push_s_out"], out[tag + "_push_r_out"] = s1, r1
+        print("%-12s %-4s nop sum %7d  worker nnz %6d  feat nnz %7d" % (name, tag, int(np.sum(nops)), wf.nnz, f.nnz))
+    np.savez_compressed(os.path.join(HERE, name + "_pagerank.npz"), **out)
+
+
+PAGERANK_GRAPHS = ["ba300", "grid25", "corner", "weighted", "selfloop", "directed", "rmat2000"]
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["small", "cli"]
+    if "pagerank" in which:
+        gs = graphs()
+        for name in PAGERANK_GRAPHS:
+            adj, rho, eps = gs[name]
+            run_pagerank_variants(name, adj, rho, eps)
     if "small" in which:
         for name, (adj, rho, eps) in graphs().items():
             run_graph(name, adj, rho, eps)
