@@ -718,6 +718,7 @@ struct arcte_hip_ctx {
     DevBuf<uint32_t> slot_epoch;
     DevBuf<int32_t> queue, sup;
     uint64_t seeds_since_clear = 0;
+    std::vector<int32_t> row_len;   // host copy of the row lengths: the work order is heaviest seed first
     // per-run
     int64_t run_nseeds = -1;
     DevBuf<int32_t> seeds_d, work_pos, out_cnt, status, nop_d;
@@ -851,6 +852,8 @@ int arcte_hip_create(int device, int64_t n, int64_t nnz, const int64_t *indptr, 
     c->device = device;
     c->n = n;
     c->nnz = nnz;
+    c->row_len.resize((size_t)n);
+    for (int64_t i = 0; i < n; i++) c->row_len[i] = (int32_t)std::min<int64_t>(indptr[i + 1] - indptr[i], INT32_MAX);
     int rc = [&]() -> int {
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, device));
@@ -1021,12 +1024,17 @@ static int run_seeds_impl(arcte_hip_ctx *c, const int64_t *seeds, int64_t nseeds
         HIP_TRY(c->raw.alloc(want));
     }
 
+    // Work order: heaviest seed first (by row length, the reference's own ordering key, arcte.py:614-616),
+    // whatever order the caller listed the seeds in; results stay in the caller's order.
     std::vector<int32_t> work((size_t)nseeds), next;   // positions (into seeds[]) still to run
     for (int64_t k = 0; k < nseeds; k++) work[k] = (int32_t)k;
+    std::stable_sort(work.begin(), work.end(), [&](int32_t a, int32_t b) {
+        return c->row_len[(size_t)seeds[a]] > c->row_len[(size_t)seeds[b]];
+    });
     std::vector<int32_t> status_h((size_t)nseeds), cnt_h((size_t)nseeds);
     std::vector<int64_t> dst_h((size_t)nseeds, 0);
     std::vector<int64_t> seg_start((size_t)nseeds, 0);   // where each seed's rows sit in rows_final (launch order)
-    bool identity = true;
+    bool identity = false;
     int64_t final_used = 0;
     double ms_push = 0, ms_compact = 0;
     int launches = 0;
@@ -1074,11 +1082,13 @@ static int run_seeds_impl(arcte_hip_ctx *c, const int64_t *seeds, int64_t nseeds
         ms_push += ms;
         for (int i = 0; i < 4; i++) c->stats[i] += (int64_t)cnt8[2 + i];
 
-        // finished seeds of this launch: their rows are appended to rows_final in work-list order
+        // finished seeds of this launch: their rows are appended to rows_final in caller (position) order
         next.clear();
         bool queue_over = false, out_over = false;
         int64_t add = 0;
-        for (int32_t pos : work) {
+        std::vector<int32_t> by_pos(work);
+        std::sort(by_pos.begin(), by_pos.end());
+        for (int32_t pos : by_pos) {
             const int32_t st = status_h[pos];
             dst_h[pos] = final_used + add;
             if (st == ST_OK) {

@@ -43,7 +43,19 @@ def calculate_epsilon_effective(rho, epsilon, seed_degree, neighbor_degrees, mea
 
 
 def _seed_matrix(n, seeds, colptr, rows):
-    cols = np.repeat(np.asarray(seeds, dtype=np.int64), np.diff(colptr))
+    """n x n CSR of ones with column seeds[k] = rows[colptr[k]:colptr[k+1]] (reference arcte.py:379-388).
+    With ascending seeds the column-compressed result IS a CSC matrix, and one linear-time transpose gives
+    the canonical CSR; any other order goes through COO like the reference does."""
+    seeds = np.asarray(seeds, dtype=np.int64)
+    if seeds.size == 0 or np.all(np.diff(seeds) > 0):
+        counts = np.zeros(n + 1, dtype=np.int64)
+        counts[seeds + 1] = np.diff(colptr)
+        indptr = np.cumsum(counts)
+        index_dtype = np.int32 if max(n, int(indptr[-1])) < 2 ** 31 else np.int64
+        features = sparse.csc_matrix((np.ones(rows.size, dtype=np.float64), rows.astype(index_dtype, copy=False),
+                                      indptr.astype(index_dtype)), shape=(n, n))
+        return features.tocsr()
+    cols = np.repeat(seeds, np.diff(colptr))
     features = sparse.coo_matrix((np.ones(rows.size, dtype=np.float64), (rows.astype(np.int64), cols)), shape=(n, n))
     return sparse.csr_matrix(features)
 
@@ -138,10 +150,11 @@ def _arcte_driver(adjacency_matrix, rho, epsilon, number_of_threads, worker):
     iterate_nodes = seed_nodes(adjacency_matrix)
 
     if n_gpus == 1 or iterate_nodes.size < 2:
-        local_features = worker(iterate_nodes, rw_transition.indices, rw_transition.indptr, rw_transition.data,
+        # the library orders the work heaviest-first by itself; ascending ids make the result a CSC matrix
+        local_features = worker(np.sort(iterate_nodes), rw_transition.indices, rw_transition.indptr, rw_transition.data,
                                 out_degree, in_degree, rho, epsilon)
     else:
-        chunks = [c for c in parallel_chunks(iterate_nodes, n_gpus)]
+        chunks = [None if c is None else np.sort(c) for c in parallel_chunks(iterate_nodes, n_gpus)]
         results = [None] * n_gpus
         errors = []
 
