@@ -1024,6 +1024,14 @@ static int run_seeds_impl(arcte_hip_ctx *c, const int64_t *seeds, int64_t nseeds
         HIP_TRY(c->raw.alloc(want));
     }
 
+    if (use_effective_epsilon) {
+        // calculate_epsilon_effective reduces over the seed's out-neighbours (arcte.py:32,39-40): with none
+        // numpy raises "zero-size array to reduction operation maximum which has no identity"
+        for (int64_t k = 0; k < nseeds; k++)
+            if (c->row_len[(size_t)seeds[k]] == 0)
+                return fail(ARCTE_HIP_EGRAPH, "seed " + std::to_string(seeds[k]) +
+                                                  " has no out-neighbours: the effective epsilon is undefined (the reference raises at arcte.py:39)");
+    }
     // Work order: heaviest seed first (by row length, the reference's own ordering key, arcte.py:614-616),
     // whatever order the caller listed the seeds in; results stay in the caller's order.
     std::vector<int32_t> work((size_t)nseeds), next;   // positions (into seeds[]) still to run
