@@ -274,3 +274,17 @@ def test_full_size_1m_graph_properties_and_sampled_oracle_parity():
     assert np.array_equal(np.diff(o_colptr), sizes[pick])
     for j, k in enumerate(pick):
         assert np.array_equal(np.sort(rows[colptr[k]:colptr[k + 1]]), o_rows[o_colptr[j]:o_colptr[j + 1]])
+
+
+def test_seed_without_out_neighbours_is_rejected_like_the_reference():
+    """calculate_epsilon_effective on an empty neighbourhood raises in the reference (np.max of an empty
+    array, arcte.py:39); directed input is the only way to get there (the pipeline symmetrises)."""
+    a = sparse.csr_matrix(np.array([[0, 1, 1], [1, 0, 1], [0, 0, 0]], dtype=np.float64))   # node 2: in-count 2, no out-edges
+    w, od, idg = get_natural_random_walk_matrix(a)
+    with _native.Context(w.indptr, w.indices, w.data, od, idg) as ctx:
+        with pytest.raises(_native.ArcteHipError) as e:
+            ctx.run_seeds(np.array([2]), 0.1, 1e-5)
+        assert e.value.code == -5
+        ctx.run_seeds(np.array([2]), 0.1, 1e-5, use_effective_epsilon=False)    # raw epsilon needs no neighbours
+        colptr, rows, nop = ctx.fetch(want_nop=True)
+        assert nop.tolist() == [1] and rows.size == 0
