@@ -159,6 +159,14 @@ int arcte_hip_push_variant(int device, int64_t n, double *s, double *r,
                            const double *w_i, const int32_t *a_i, int64_t deg,
                            int64_t push_node, double rho, int variant, double laziness_factor);
 
+/*
+ * Arithmetic of the propagation kernels on this context: 0 = float64 (default; the reference's type, the
+ * only one held to bit-exact parity), 1 = float32 (BASELINE.json configs[4] tolerance sweep: 16-byte state
+ * entries, float weights/degrees; the effective epsilon is still computed in float64 and rounded once).
+ * Takes effect from the next run; switching clears the per-slot state.
+ */
+int arcte_hip_set_float32(arcte_hip_ctx *ctx, int enable);
+
 /* Properties of the context: info[0] slots, [1] queue capacity, [2] device bytes held,
  * [3] compute units, [4] wavefronts per workgroup. */
 int arcte_hip_info(arcte_hip_ctx *ctx, int64_t info[5]);

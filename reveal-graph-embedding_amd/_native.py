@@ -41,6 +41,7 @@ SIGNATURES = {
     "arcte_hip_push_variant": (C.c_int, [C.c_int, C.c_int64, _f64p, _f64p, _f64p, _i32p, C.c_int64, C.c_int64, C.c_double,
                                          C.c_int, C.c_double]),
     "arcte_hip_push": (C.c_int, [C.c_int, C.c_int64, _f64p, _f64p, _f64p, _i32p, C.c_int64, C.c_int64, C.c_double]),
+    "arcte_hip_set_float32": (C.c_int, [C.c_void_p, C.c_int]),
     "arcte_hip_info": (C.c_int, [C.c_void_p, _i64p]),
 }
 
@@ -122,6 +123,10 @@ class Context:
 
     def __exit__(self, *exc):
         self.close()
+
+    def set_float32(self, enable=True):
+        """Switch the propagation arithmetic to float32 (tolerance sweep) or back to float64 (default)."""
+        _check(lib().arcte_hip_set_float32(self._h, 1 if enable else 0))
 
     def epsilon_effective(self, seeds, epsilon):
         seeds = np.ascontiguousarray(seeds, dtype=np.int64)

@@ -92,6 +92,7 @@ struct GraphDev {
     const double *out_degree;
     const double *in_degree;
     const double *edge_in_degree;   // in_degree[indices[k]] stored with the edge: streams with the row
+    const float *data_f, *in_degree_f, *edge_in_degree_f;   // float32 copies (NULL until float32 is switched on)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -215,30 +216,72 @@ __global__ __launch_bounds__(BLOCK) void k_epsilon_effective(GraphDev g, const i
 // Dense per-slot state, one 32-byte sector per node.  An entry is live only while its epoch equals
 // the slot's current epoch (one epoch per seed), so "s[:] = 0; r[:] = 0" (arcte.py:337-338) costs
 // nothing and first touches are recognised without a separate bitmap.
-struct __attribute__((aligned(32))) Entry {
+template <typename T> struct EntryT;
+template <> struct __attribute__((aligned(32))) EntryT<double> {
     double r;
     double s;
     double d;         // in_degree of the node (threshold tests and the degree normalisation)
     uint32_t epoch;
     uint32_t pad;
 };
+// float32 flavour (BASELINE.json configs[4] tolerance sweep): one 16-byte entry per node
+template <> struct __attribute__((aligned(16))) EntryT<float> {
+    float r;
+    float s;
+    float d;
+    uint32_t epoch;
+};
+typedef EntryT<double> Entry;
 static_assert(sizeof(Entry) == 32, "Entry must be one 32-byte sector");
+static_assert(sizeof(EntryT<float>) == 16, "float entry must be 16 bytes");
 
-struct EntryLo { double r, s; };
-struct EntryHi { double d; uint32_t epoch, pad; };
+template <typename T> struct LoT { T r, s; };
+template <typename T> struct HiT { T d; uint32_t epoch; };
 
-__device__ __forceinline__ EntryLo load_lo(const Entry *e) { double2 t = *reinterpret_cast<const double2 *>(e); return {t.x, t.y}; }
-__device__ __forceinline__ EntryHi load_hi(const Entry *e)
+__device__ __forceinline__ LoT<double> load_lo(const EntryT<double> *e) { double2 t = *reinterpret_cast<const double2 *>(e); return {t.x, t.y}; }
+__device__ __forceinline__ HiT<double> load_hi(const EntryT<double> *e)
 {
     double2 t = *(reinterpret_cast<const double2 *>(e) + 1);
-    uint64_t bits = (uint64_t)__double_as_longlong(t.y);
-    return {t.x, (uint32_t)bits, (uint32_t)(bits >> 32)};
+    return {t.x, (uint32_t)(uint64_t)__double_as_longlong(t.y)};
 }
-__device__ __forceinline__ void store_lo(Entry *e, double r, double s) { *reinterpret_cast<double2 *>(e) = make_double2(r, s); }
-__device__ __forceinline__ void store_hi(Entry *e, double d, uint32_t epoch)
+__device__ __forceinline__ void store_lo(EntryT<double> *e, double r, double s) { *reinterpret_cast<double2 *>(e) = make_double2(r, s); }
+__device__ __forceinline__ void store_hi(EntryT<double> *e, double d, uint32_t epoch)
 {
     *(reinterpret_cast<double2 *>(e) + 1) = make_double2(d, __longlong_as_double((long long)(uint64_t)epoch));
 }
+__device__ __forceinline__ LoT<float> load_lo(const EntryT<float> *e) { float2 t = *reinterpret_cast<const float2 *>(e); return {t.x, t.y}; }
+__device__ __forceinline__ HiT<float> load_hi(const EntryT<float> *e)
+{
+    float2 t = *(reinterpret_cast<const float2 *>(e) + 1);
+    return {t.x, __float_as_uint(t.y)};
+}
+__device__ __forceinline__ void store_lo(EntryT<float> *e, float r, float s) { *reinterpret_cast<float2 *>(e) = make_float2(r, s); }
+__device__ __forceinline__ void store_hi(EntryT<float> *e, float d, uint32_t epoch)
+{
+    *(reinterpret_cast<float2 *>(e) + 1) = make_float2(d, __uint_as_float(epoch));
+}
+
+// the float64 / float32 views of the graph's value arrays
+template <typename T> struct GraphValues { const T *data, *in_degree, *edge_in_degree; };
+template <typename T> __device__ __forceinline__ GraphValues<T> graph_values(const GraphDev &g);
+template <> __device__ __forceinline__ GraphValues<double> graph_values<double>(const GraphDev &g) { return {g.data, g.in_degree, g.edge_in_degree}; }
+template <> __device__ __forceinline__ GraphValues<float> graph_values<float>(const GraphDev &g) { return {g.data_f, g.in_degree_f, g.edge_in_degree_f}; }
+
+template <typename T> __device__ __forceinline__ T shfl_real(T v, int src);
+template <> __device__ __forceinline__ double shfl_real<double>(double v, int src) { return shfl_f64(v, src); }
+template <> __device__ __forceinline__ float shfl_real<float>(float v, int src) { return __shfl(v, src, WAVE); }
+template <typename T> __device__ __forceinline__ T wave_min_real(T x)
+{
+    for (int o = 32; o > 0; o >>= 1) {
+        T y = __shfl_xor(x, o, WAVE);
+        x = (y < x) ? y : x;
+    }
+    return x;
+}
+// margin of the candidate bound: far above one rounding error of the type, far below any real gap
+template <typename T> __device__ __forceinline__ T cand_margin();
+template <> __device__ __forceinline__ double cand_margin<double>() { return 1.0 - 0x1p-40; }
+template <> __device__ __forceinline__ float cand_margin<float>() { return 1.0f - 0x1p-16f; }
 
 struct PushParams {
     GraphDev g;
@@ -252,7 +295,7 @@ struct PushParams {
     double rho;        // PageRank flavours: s[u] += rho*r[u]
     double lazy;       // lazy flavour: laziness factor
     // per-slot scratch
-    Entry *state;      // [slots][n]
+    void *state;       // [slots][n] EntryT<T>
     uint32_t *slot_epoch;   // [slots] last epoch used by the slot
     int32_t *queue;    // [slots][qcap]
     int32_t *sup;      // [slots][n]   candidate list (see cand_thr)
@@ -274,18 +317,19 @@ struct PushParams {
 // VAR 0: cumulative PageRank difference (push.py:41-64, similarity.py:149-222) -- ARCTE proper.
 // VAR 1: PageRank limit push (push.py:4-17, similarity.py:11-63).
 // VAR 2: lazy PageRank push (push.py:20-38, similarity.py:66-146) with its self re-push loops.
-template <int MODE, int VAR>
+template <int MODE, int VAR, typename T>
 __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
 {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int64_t slot = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wave;
     const GraphDev &g = P.g;
-    Entry *__restrict__ st = P.state + slot * g.n;
+    const GraphValues<T> gv = graph_values<T>(g);
+    EntryT<T> *__restrict__ st = reinterpret_cast<EntryT<T> *>(P.state) + slot * g.n;
     int32_t *__restrict__ q = P.queue + slot * (int64_t)P.qcap;
     int32_t *__restrict__ sup = P.sup + slot * g.n;
     const uint32_t qmask = P.qcap - 1;
-    const double omr = P.one_minus_rho;
+    const T omr = (T)P.one_minus_rho;
     uint32_t epoch = P.slot_epoch[slot];
 
     // Dynamic seed queue: lane 0 draws the next work item, the wave broadcasts it.  The
@@ -301,7 +345,7 @@ __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
     for (unsigned long long wk = next_work(); wk < (unsigned long long)P.nwork; wk = next_work()) {
         const int32_t pos = P.work_pos ? P.work_pos[wk] : (int32_t)wk;
         const int32_t seed = P.seeds[pos];
-        const double eps = P.eps[pos];
+        const T eps = (T)P.eps[pos];
         if (MODE == 0) {
             // the arena is already full: this seed is re-run by the host after the arena is drained
             unsigned long long cur = 0;
@@ -323,30 +367,30 @@ __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
         uint32_t head = 0, tail = 0;       // ring counters (wave-uniform)
         int32_t nsup = 0;          // candidates
         int32_t nfirst = 0;        // nodes with s != 0 (the support of the similarity slice)
-        double cand_thr = 0.0;
+        T cand_thr = T(0);
         int32_t npush = 0;
         unsigned long long nedges = 0;
         bool ok = true, runaway = false;
 
         // ---- one push of node u (push.py:41-64) followed by the ordered enqueue of
         //      similarity.py:194-196 / :214-216.  `ru` is r[u] at pop time.
-        auto push = [&](int32_t u, double ru, int64_t rb, int64_t re, bool do_enqueue) {
-            double c;            // what every neighbour receives per unit of transition weight
-            double r_self;       // r[u] right after the push bookkeeping (what a self-loop lane adds to)
+        auto push = [&](int32_t u, T ru, int64_t rb, int64_t re, bool do_enqueue) {
+            T c;            // what every neighbour receives per unit of transition weight
+            T r_self;       // r[u] right after the push bookkeeping (what a self-loop lane adds to)
             if (VAR == 0) {
                 c = omr * ru;                                    // push.py:56
-                r_self = 0.0;
-                if (lane == 0) st[u].r = 0.0;                    // push.py:59
+                r_self = T(0);
+                if (lane == 0) st[u].r = T(0);                    // push.py:59
             } else {
-                const double A = P.rho * ru;                     // push.py:10 / :29
-                if (VAR == 1) { c = omr * ru; r_self = 0.0; }                                  // push.py:11,15
-                else { c = omr * (1 - P.lazy) * ru; r_self = omr * P.lazy * (ru); }            // push.py:30-31
+                const T A = (T)P.rho * ru;                     // push.py:10 / :29
+                if (VAR == 1) { c = omr * ru; r_self = T(0); }                                  // push.py:11,15
+                else { c = omr * (1 - (T)P.lazy) * ru; r_self = omr * (T)P.lazy * (ru); }            // push.py:30-31
                 bool grew = false;
                 if (lane == 0) {
-                    const double s_old = st[u].s;                // u is live: it was deposited to, or is the seed
-                    const double s_new = s_old + A;              // push.py:14 / :34
+                    const T s_old = st[u].s;                // u is live: it was deposited to, or is the seed
+                    const T s_new = s_old + A;              // push.py:14 / :34
                     store_lo(st + u, r_self, s_new);             // push.py:15 / :35
-                    grew = s_old == 0.0 && s_new != 0.0;
+                    grew = s_old == T(0) && s_new != T(0);
                     if (grew) sup[nsup] = u;                     // s is non-zero exactly at pushed nodes
                 }
                 const int g1 = __popcll(__ballot(grew));
@@ -357,26 +401,26 @@ __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
                 const int64_t k0 = base + lane, k1 = k0 + WAVE;
                 const bool a0 = k0 < re, a1 = k1 < re;
                 int32_t v0 = 0, v1 = 0;
-                double w0 = 0.0, w1 = 0.0, d0 = 1.0, d1 = 1.0;
-                if (a0) { v0 = g.indices[k0]; w0 = g.data[k0]; d0 = g.edge_in_degree[k0]; }
-                if (a1) { v1 = g.indices[k1]; w1 = g.data[k1]; d1 = g.edge_in_degree[k1]; }
-                EntryLo l0 = {0.0, 0.0}, l1 = {0.0, 0.0};
-                EntryHi h0 = {1.0, 0u, 0u}, h1 = {1.0, 0u, 0u};
+                T w0 = T(0), w1 = T(0), d0 = T(1), d1 = T(1);
+                if (a0) { v0 = g.indices[k0]; w0 = gv.data[k0]; d0 = gv.edge_in_degree[k0]; }
+                if (a1) { v1 = g.indices[k1]; w1 = gv.data[k1]; d1 = gv.edge_in_degree[k1]; }
+                LoT<T> l0 = {T(0), T(0)}, l1 = {T(0), T(0)};
+                HiT<T> h0 = {T(1), 0u}, h1 = {T(1), 0u};
                 if (a0) { l0 = load_lo(st + v0); h0 = load_hi(st + v0); }
                 if (a1) { l1 = load_lo(st + v1); h1 = load_hi(st + v1); }
 #pragma unroll
                 for (int t = 0; t < 2; t++) {
                     const bool act = t ? a1 : a0;
                     const int32_t v = t ? v1 : v0;
-                    const double w = t ? w1 : w0;
-                    const double dv = t ? d1 : d0;
-                    const EntryLo lo = t ? l1 : l0;
+                    const T w = t ? w1 : w0;
+                    const T dv = t ? d1 : d0;
+                    const LoT<T> lo = t ? l1 : l0;
                     const bool live = (t ? h1.epoch : h0.epoch) == epoch;
-                    const double p = c * w;                                  // push.py:62 / :17 / :38
-                    const double r_old = live ? ((v != u) ? lo.r : r_self) : 0.0;   // a self-loop sees r[u] as just set
-                    const double s_old = live ? lo.s : 0.0;
-                    const double r_new = r_old + p;                          // push.py:64
-                    const double s_new = (VAR == 0) ? s_old + p : s_old;     // push.py:63 (ARCTE only)
+                    const T p = c * w;                                  // push.py:62 / :17 / :38
+                    const T r_old = live ? ((v != u) ? lo.r : r_self) : T(0);   // a self-loop sees r[u] as just set
+                    const T s_old = live ? lo.s : T(0);
+                    const T r_new = r_old + p;                          // push.py:64
+                    const T s_new = (VAR == 0) ? s_old + p : s_old;     // push.py:63 (ARCTE only)
                     if (act) {
                         store_lo(st + v, r_new, s_new);
                         if (!live) store_hi(st + v, dv, epoch);
@@ -385,12 +429,12 @@ __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
                         // Candidate list: every node whose s/in_degree has reached cand_thr, a lower bound of
                         // the final selection threshold (s only grows, so each node crosses once).  It replaces
                         // the full touched list: extraction only has to look at candidates.
-                        const double bar = cand_thr * dv;
-                        const bool cross = act && (s_new > 0.0 && s_new >= bar) && !(s_old > 0.0 && s_old >= bar);
+                        const T bar = cand_thr * dv;
+                        const bool cross = act && (s_new > T(0) && s_new >= bar) && !(s_old > T(0) && s_old >= bar);
                         const uint64_t mc = __ballot(cross);
                         if (cross) sup[nsup + lane_below(mc)] = v;
                         nsup += __popcll(mc);
-                        nfirst += __popcll(__ballot(act && s_old == 0.0 && s_new != 0.0));   // support of s grows
+                        nfirst += __popcll(__ballot(act && s_old == T(0) && s_new != T(0)));   // support of s grows
                     }
                     if (!do_enqueue) continue;
                     const bool enq = act && (r_new / dv >= eps);             // similarity.py:194/214
@@ -413,11 +457,11 @@ __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
 
         // ---- similarity.py:176-192: s[seed] = r[seed] = 1, one unconditional push
         const int64_t seed_b = g.indptr[seed], seed_e = g.indptr[seed + 1];
-        const double seed_d = g.in_degree[seed];
+        const T seed_d = gv.in_degree[seed];
         if (lane == 0) {
-            if (VAR == 0) store_lo(st + seed, 1.0, 1.0);         // similarity.py:176-177
-            else if (MODE == 0) store_lo(st + seed, 1.0, 0.0);   // similarity.py:26 / :85: only r[seed] = 1
-            else st[seed].r = 1.0;                                //   (MODE 1: the caller's s[seed] stays)
+            if (VAR == 0) store_lo(st + seed, T(1), T(1));         // similarity.py:176-177
+            else if (MODE == 0) store_lo(st + seed, T(1), T(0));   // similarity.py:26 / :85: only r[seed] = 1
+            else st[seed].r = T(1);                                //   (MODE 1: the caller's s[seed] stays)
             if (MODE == 0) store_hi(st + seed, seed_d, epoch);   // MODE 1: the host made every entry live
             if (VAR == 0) sup[0] = seed;
         }
@@ -428,20 +472,20 @@ __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
             // s/in_degree over the closed neighbourhood at the END; s never decreases, so the minimum
             // right after the first push (s[b] = c*w_b, s[seed] >= 1) bounds it from below.  Scaled down a
             // hair so that the cheap product test s >= cand_thr*d admits everything the exact division does.
-            double lb = 1.0 / seed_d;
-            const double c0 = omr * 1.0;
+            T lb = T(1) / seed_d;
+            const T c0 = omr * T(1);
             for (int64_t k = seed_b + lane; k < seed_e; k += WAVE) {
-                const double x = (c0 * g.data[k]) / g.edge_in_degree[k];
+                const T x = (c0 * gv.data[k]) / gv.edge_in_degree[k];
                 lb = (x < lb) ? x : lb;
             }
-            cand_thr = wave_min(lb) * (1.0 - 0x1p-40);
+            cand_thr = wave_min_real<T>(lb) * cand_margin<T>();
         }
         // (PageRank flavours: s is non-zero only at pushed nodes; the candidate list is the pushed nodes)
-        push(seed, 1.0, seed_b, seed_e, true);
+        push(seed, T(1), seed_b, seed_e, true);
         if (VAR == 2) {
             // similarity.py:108-116: re-push the seed while it stays above the threshold, no enqueue
             while (ok) {
-                const double ru2 = st[seed].r;
+                const T ru2 = st[seed].r;
                 if (!(ru2 / seed_d >= eps)) break;
                 push(seed, ru2, seed_b, seed_e, false);
             }
@@ -456,7 +500,7 @@ __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
             const uint32_t bn = navail < (uint32_t)WAVE ? navail : (uint32_t)WAVE;
             const bool valid = (uint32_t)lane < bn;
             int32_t u_l = 0;
-            double r_l = 0.0, d_l = 1.0;
+            T r_l = T(0), d_l = T(1);
             int64_t rb_l = 0, re_l = 0;
             if (valid) {
                 u_l = q[(head + lane) & qmask];
@@ -473,16 +517,16 @@ __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
                 if (m == 0) break;
                 const int i = __ffsll((unsigned long long)m) - 1;
                 const int32_t u = __shfl(u_l, i, WAVE);
-                const double ru = shfl_f64(r_l, i);
+                const T ru = shfl_real<T>(r_l, i);
                 const int64_t rb = shfl_i64(rb_l, i);
                 const int64_t re = shfl_i64(re_l, i);
                 consumed = i + 1;
                 push(u, ru, rb, re, true);
                 if (VAR == 2) {
                     // similarity.py:136-144: re-push the same node while it stays above the threshold
-                    const double du = shfl_f64(d_l, i);
+                    const T du = shfl_real<T>(d_l, i);
                     while (ok) {
-                        const double ru2 = st[u].r;
+                        const T ru2 = st[u].r;
                         if (!(ru2 / du >= eps)) break;
                         push(u, ru2, rb, re, false);
                     }
@@ -500,19 +544,19 @@ __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
         unsigned long long off = 0;
         if (MODE == 0 && ok) {
             const int64_t sb = g.indptr[seed], se = g.indptr[seed + 1];
-            double thr = st[seed].s / st[seed].d;
-            bool miss = st[seed].s == 0.0, selfloop = false;
+            T thr = st[seed].s / st[seed].d;
+            bool miss = st[seed].s == T(0), selfloop = false;
             for (int64_t k = sb + lane; k < se; k += WAVE) {
                 const int32_t v = g.indices[k];
                 selfloop |= (v == seed);
-                const EntryLo lo = load_lo(st + v);
-                const EntryHi hi = load_hi(st + v);
-                const double sv = (hi.epoch == epoch) ? lo.s : 0.0;
-                miss |= (sv == 0.0);
-                const double x = sv / g.edge_in_degree[k];
+                const LoT<T> lo = load_lo(st + v);
+                const HiT<T> hi = load_hi(st + v);
+                const T sv = (hi.epoch == epoch) ? lo.s : T(0);
+                miss |= (sv == T(0));
+                const T x = sv / gv.edge_in_degree[k];
                 thr = (x < thr) ? x : thr;
             }
-            thr = wave_min(thr);
+            thr = wave_min_real<T>(thr);
             const bool missing = __ballot(miss) != 0;
             if (VAR == 0 && missing) sta = ST_MISSING_BASE;
             else if (VAR != 0 && (missing || __ballot(selfloop) != 0)) {
@@ -580,26 +624,36 @@ __global__ __launch_bounds__(BLOCK) void k_gather_segments(const int32_t *src, c
 }
 
 // caller's dense s, r -> slot 0, every entry live in the epoch the slice kernel is about to use
-__global__ void k_state_from_dense(const double *s, const double *r, const double *in_degree, Entry *st,
+template <typename T>
+__global__ void k_state_from_dense(const double *s, const double *r, const double *in_degree, void *state,
                                    const uint32_t *slot_epoch, int64_t n)
 {
+    EntryT<T> *st = reinterpret_cast<EntryT<T> *>(state);
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
-        store_lo(st + i, r[i], s[i]);
-        store_hi(st + i, in_degree[i], slot_epoch[0] + 1);
+        store_lo(st + i, (T)r[i], (T)s[i]);
+        store_hi(st + i, (T)in_degree[i], slot_epoch[0] + 1);
     }
 }
 
 // slot 0 -> dense s, r (slot_epoch[0] is the epoch the slice kernel just used)
-__global__ void k_state_to_dense(const Entry *st, const uint32_t *slot_epoch, double *s, double *r, int64_t n)
+template <typename T>
+__global__ void k_state_to_dense(const void *state, const uint32_t *slot_epoch, double *s, double *r, int64_t n)
 {
+    const EntryT<T> *st = reinterpret_cast<const EntryT<T> *>(state);
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
-        const EntryLo lo = load_lo(st + i);
+        const LoT<T> lo = load_lo(st + i);
         const bool live = load_hi(st + i).epoch == slot_epoch[0];
-        r[i] = live ? lo.r : 0.0;
-        s[i] = live ? lo.s : 0.0;
+        r[i] = live ? (double)lo.r : 0.0;
+        s[i] = live ? (double)lo.s : 0.0;
     }
+}
+
+__global__ void k_to_float(const double *in, float *out, int64_t n)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (float)in[i];
 }
 
 // in_degree[indices[k]] for every stored edge
@@ -711,6 +765,9 @@ struct arcte_hip_ctx {
     DevBuf<int64_t> indptr;
     DevBuf<int32_t> indices;
     DevBuf<double> data, out_degree, in_degree, edge_in_degree;
+    DevBuf<float> data_f, in_degree_f, edge_in_degree_f;
+    int float32 = 0;        // arithmetic type of the propagation kernels
+    int state_is_f32 = 0;   // layout the state buffer currently holds
     // slots
     int64_t slots = 0;
     uint32_t qcap = 0;
@@ -742,11 +799,14 @@ struct arcte_hip_ctx {
         g.out_degree = out_degree.p;
         g.in_degree = in_degree.p;
         g.edge_in_degree = edge_in_degree.p;
+        g.data_f = data_f.p;
+        g.in_degree_f = in_degree_f.p;
+        g.edge_in_degree_f = edge_in_degree_f.p;
         return g;
     }
     size_t device_bytes() const
     {
-        return indptr.bytes() + indices.bytes() + data.bytes() + out_degree.bytes() + in_degree.bytes() + edge_in_degree.bytes() + state.bytes() + slot_epoch.bytes() +
+        return indptr.bytes() + indices.bytes() + data.bytes() + out_degree.bytes() + in_degree.bytes() + edge_in_degree.bytes() + data_f.bytes() + in_degree_f.bytes() + edge_in_degree_f.bytes() + state.bytes() + slot_epoch.bytes() +
                queue.bytes() + sup.bytes() + seeds_d.bytes() + work_pos.bytes() + out_cnt.bytes() + status.bytes() +
                nop_d.bytes() + eps_d.bytes() + out_off.bytes() + dst_off.bytes() + raw.bytes() + rows_final.bytes();
     }
@@ -763,6 +823,7 @@ int alloc_slots(arcte_hip_ctx *c, int64_t slots, uint32_t qcap)
     HIP_TRY(hipMemsetAsync(c->state.p, 0, c->state.bytes(), c->stream));
     HIP_TRY(hipMemsetAsync(c->slot_epoch.p, 0, c->slot_epoch.bytes(), c->stream));
     c->seeds_since_clear = 0;
+    c->state_is_f32 = c->float32;
     c->slots = slots;
     c->qcap = qcap;
     return 0;
@@ -788,7 +849,7 @@ int grow_queue(arcte_hip_ctx *c)
     return 0;
 }
 
-template <int MODE, int VAR>
+template <int MODE, int VAR, typename T>
 int launch_seeds_v(arcte_hip_ctx *c, const PushParams &P, int64_t nwork)
 {
     int64_t waves = std::min<int64_t>(c->slots, std::max<int64_t>(nwork, 1));
@@ -796,24 +857,57 @@ int launch_seeds_v(arcte_hip_ctx *c, const PushParams &P, int64_t nwork)
     // MODE 1 works on the dense vectors the host placed in slot 0: exactly one wavefront may run
     const int threads = (MODE == 1) ? WAVE : BLOCK;
     if (MODE == 1) blocks = 1;
-    hipLaunchKernelGGL((k_arcte_seeds<MODE, VAR>), dim3(blocks), dim3(threads), 0, c->stream, P);
+    hipLaunchKernelGGL((k_arcte_seeds<MODE, VAR, T>), dim3(blocks), dim3(threads), 0, c->stream, P);
     HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+template <int MODE, typename T>
+int launch_seeds_t(arcte_hip_ctx *c, const PushParams &P, int64_t nwork, int variant)
+{
+    if (variant == 1) return launch_seeds_v<MODE, 1, T>(c, P, nwork);
+    if (variant == 2) return launch_seeds_v<MODE, 2, T>(c, P, nwork);
+    return launch_seeds_v<MODE, 0, T>(c, P, nwork);
+}
+
+// The state buffer holds either 32-byte float64 entries or 16-byte float32 entries; stale bytes of the other
+// layout could alias a live epoch, so a switch of arithmetic clears it.
+int prepare_precision(arcte_hip_ctx *c)
+{
+    if (c->float32 && !c->data_f.p) {
+        HIP_TRY(c->data_f.alloc(c->nnz));
+        HIP_TRY(c->edge_in_degree_f.alloc(c->nnz));
+        HIP_TRY(c->in_degree_f.alloc(c->n));
+        const int tb = 256;
+        if (c->nnz) {
+            hipLaunchKernelGGL(k_to_float, dim3((unsigned)((c->nnz + tb - 1) / tb)), dim3(tb), 0, c->stream, c->data.p, c->data_f.p, c->nnz);
+            hipLaunchKernelGGL(k_to_float, dim3((unsigned)((c->nnz + tb - 1) / tb)), dim3(tb), 0, c->stream, c->edge_in_degree.p,
+                               c->edge_in_degree_f.p, c->nnz);
+        }
+        hipLaunchKernelGGL(k_to_float, dim3((unsigned)((c->n + tb - 1) / tb)), dim3(tb), 0, c->stream, c->in_degree.p, c->in_degree_f.p, c->n);
+        HIP_TRY(hipGetLastError());
+    }
+    if (c->state_is_f32 != c->float32) {
+        HIP_TRY(hipMemsetAsync(c->state.p, 0, c->state.bytes(), c->stream));
+        HIP_TRY(hipMemsetAsync(c->slot_epoch.p, 0, c->slot_epoch.bytes(), c->stream));
+        c->seeds_since_clear = 0;
+        c->state_is_f32 = c->float32;
+    }
     return 0;
 }
 
 template <int MODE>
 int launch_seeds(arcte_hip_ctx *c, const PushParams &P, int64_t nwork, int variant)
 {
-    if (variant == 1) return launch_seeds_v<MODE, 1>(c, P, nwork);
-    if (variant == 2) return launch_seeds_v<MODE, 2>(c, P, nwork);
-    return launch_seeds_v<MODE, 0>(c, P, nwork);
+    if (c->float32) return launch_seeds_t<MODE, float>(c, P, nwork, variant);
+    return launch_seeds_t<MODE, double>(c, P, nwork, variant);
 }
 
 }  // namespace
 
 extern "C" {
 
-int arcte_hip_abi_version(void) { return 2; }
+int arcte_hip_abi_version(void) { return 3; }
 
 const char *arcte_hip_last_error(void) { return g_err.c_str(); }
 
@@ -882,7 +976,7 @@ int arcte_hip_create(int device, int64_t n, int64_t nnz, const int64_t *indptr, 
         int64_t slots = n_slots;
         if (slots <= 0) {
             int per_cu = 0;
-            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (k_arcte_seeds<0, 0>), BLOCK, 0));
+            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (k_arcte_seeds<0, 0, double>), BLOCK, 0));
             per_cu = std::max(1, std::min(per_cu, 8));
             slots = (int64_t)per_cu * c->cus * WAVES_PER_BLOCK;
             // keep the slot scratch within a fixed share of the device
@@ -915,7 +1009,7 @@ int arcte_hip_destroy(arcte_hip_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     c->indptr.release(); c->indices.release(); c->data.release(); c->out_degree.release(); c->in_degree.release();
-    c->state.release(); c->slot_epoch.release(); c->edge_in_degree.release(); c->queue.release(); c->sup.release();
+    c->state.release(); c->slot_epoch.release(); c->edge_in_degree.release(); c->data_f.release(); c->in_degree_f.release(); c->edge_in_degree_f.release(); c->queue.release(); c->sup.release();
     c->seeds_d.release(); c->work_pos.release(); c->out_cnt.release(); c->status.release(); c->nop_d.release();
     c->eps_d.release(); c->out_off.release(); c->dst_off.release(); c->counters.release();
     c->raw.release(); c->rows_final.release();
@@ -971,6 +1065,10 @@ static int run_seeds_impl(arcte_hip_ctx *c, const int64_t *seeds, int64_t nseeds
     HIP_TRY(hipSetDevice(c->device));
     auto t0 = std::chrono::steady_clock::now();
     c->run_nseeds = -1;
+    {
+        int rp = prepare_precision(c);
+        if (rp) return rp;
+    }
     c->final_rows = 0;
     for (auto &s : c->stats) s = 0;
     for (auto &m : c->ms) m = 0;
@@ -1061,7 +1159,7 @@ static int run_seeds_impl(arcte_hip_ctx *c, const int64_t *seeds, int64_t nseeds
         P.one_minus_rho = 1 - rho;
         P.rho = rho;
         P.lazy = lazy;
-        P.state = c->state.p;
+        P.state = (void *)c->state.p;
         P.slot_epoch = c->slot_epoch.p;
         P.queue = c->queue.p;
         P.sup = c->sup.p;
@@ -1272,6 +1370,10 @@ static int similarity_slice_impl(arcte_hip_ctx *c, int64_t seed, double rho, dou
     if (seed < 0 || seed >= c->n) return fail(ARCTE_HIP_EINVAL, "seed id out of range");
     HIP_TRY(hipSetDevice(c->device));
     c->run_nseeds = -1;
+    {
+        int rp = prepare_precision(c);
+        if (rp) return rp;
+    }
     const int64_t n = c->n;
     DevBuf<double> sd, rd;
     DevBuf<int32_t> seed_d, small;     // small: cnt, status, nop
@@ -1291,8 +1393,12 @@ static int similarity_slice_impl(arcte_hip_ctx *c, int64_t seed, double rho, dou
             HIP_TRY(hipMemcpyAsync(sd.p, s, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
             HIP_TRY(hipMemcpyAsync(rd.p, r, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
             const int tb = 256;
-            hipLaunchKernelGGL(k_state_from_dense, dim3((unsigned)((n + tb - 1) / tb)), dim3(tb), 0, c->stream, sd.p, rd.p,
-                               c->in_degree.p, c->state.p, c->slot_epoch.p, n);
+            if (c->float32)
+                hipLaunchKernelGGL(k_state_from_dense<float>, dim3((unsigned)((n + tb - 1) / tb)), dim3(tb), 0, c->stream, sd.p, rd.p,
+                                   c->in_degree.p, (void *)c->state.p, c->slot_epoch.p, n);
+            else
+                hipLaunchKernelGGL(k_state_from_dense<double>, dim3((unsigned)((n + tb - 1) / tb)), dim3(tb), 0, c->stream, sd.p, rd.p,
+                                   c->in_degree.p, (void *)c->state.p, c->slot_epoch.p, n);
             HIP_TRY(hipMemsetAsync(c->counters.p, 0, 8 * sizeof(unsigned long long), c->stream));
             PushParams P;
             P.g = c->graph();
@@ -1304,7 +1410,7 @@ static int similarity_slice_impl(arcte_hip_ctx *c, int64_t seed, double rho, dou
             P.one_minus_rho = 1 - rho;
             P.rho = rho;
             P.lazy = lazy;
-            P.state = c->state.p;
+            P.state = (void *)c->state.p;
         P.slot_epoch = c->slot_epoch.p;
             P.queue = c->queue.p;
             P.sup = c->sup.p;
@@ -1332,8 +1438,12 @@ static int similarity_slice_impl(arcte_hip_ctx *c, int64_t seed, double rho, dou
                 if (r2) return r2;
                 continue;
             }
-            hipLaunchKernelGGL(k_state_to_dense, dim3((unsigned)((n + tb - 1) / tb)), dim3(tb), 0, c->stream, c->state.p,
-                               c->slot_epoch.p, sd.p, rd.p, n);
+            if (c->float32)
+                hipLaunchKernelGGL(k_state_to_dense<float>, dim3((unsigned)((n + tb - 1) / tb)), dim3(tb), 0, c->stream,
+                                   (const void *)c->state.p, c->slot_epoch.p, sd.p, rd.p, n);
+            else
+                hipLaunchKernelGGL(k_state_to_dense<double>, dim3((unsigned)((n + tb - 1) / tb)), dim3(tb), 0, c->stream,
+                                   (const void *)c->state.p, c->slot_epoch.p, sd.p, rd.p, n);
             HIP_TRY(hipMemcpyAsync(s, sd.p, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(hipMemcpyAsync(r, rd.p, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
             // nothing to clean: the next seed on slot 0 runs in a new epoch
@@ -1402,6 +1512,13 @@ int arcte_hip_push_variant(int device, int64_t n, double *s, double *r, const do
                            int64_t deg, int64_t push_node, double rho, int variant, double laziness_factor)
 {
     return push_impl(device, n, s, r, w_i, a_i, deg, push_node, rho, variant, laziness_factor);
+}
+
+int arcte_hip_set_float32(arcte_hip_ctx *c, int enable)
+{
+    if (!c) return fail(ARCTE_HIP_EINVAL, "ctx is NULL");
+    c->float32 = enable ? 1 : 0;
+    return 0;
 }
 
 int arcte_hip_info(arcte_hip_ctx *c, int64_t info[5])
