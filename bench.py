@@ -96,6 +96,9 @@ def main():
     ap.add_argument("--gather", choices=["rows", "counts"], default="rows",
                     help="N>1: what rank 0 collects per step (rows = the full result)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--variant", choices=["arcte", "pagerank", "lazy"], default="arcte",
+                    help="push flavour (default: ARCTE's cumulative PageRank difference = the BASELINE metric)")
+    ap.add_argument("--float32", action="store_true", help="float32 arithmetic (tolerance sweep only; not the metric)")
     args = ap.parse_args()
 
     import torch
@@ -136,10 +139,14 @@ def main():
         rank, args.nodes, nnz, seeds.size, shard.size, info["slots"], info["device_bytes"] / 1e9))
 
     gathered_rows = 0
+    variant = {"arcte": _native.ARCTE, "pagerank": _native.PAGERANK, "lazy": _native.LAZY_PAGERANK}[args.variant]
+    run_rho = (args.rho * 0.5) / (1 - 0.5 * args.rho) if args.variant == "lazy" else args.rho   # arcte.py:109
+    if args.float32:
+        ctx.set_float32(True)
 
     def step():
         nonlocal gathered_rows
-        ctx.run_seeds(shard, args.rho, args.epsilon, use_effective_epsilon=True)
+        ctx.run_seeds(shard, run_rho, args.epsilon, use_effective_epsilon=True, variant=variant)
         if world > 1:
             _, total = ctx.result_sizes()
             counts_t = torch.from_numpy(np.diff(ctx.colptr())).to(dev)
@@ -186,7 +193,7 @@ def main():
         achieved = alg / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
         traffic = None
         pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc_path):
+        if os.path.exists(pmc_path) and args.variant == "arcte" and not args.float32:
             try:
                 pmc = json.load(open(pmc_path))
                 key = "n%d_m%d_shards%d" % (args.nodes, args.edges, args.shards)
@@ -205,7 +212,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f64",
+            "dtype": "f32" if args.float32 else "f64",
             "data": "synthetic",
             "config": {
                 "workload": "R-MAT n=%d m=%d (nnz %d, %d seeds), rho=%g eps=%g; step = seed shard %s of %d (round-robin "
@@ -213,6 +220,7 @@ def main():
                             % (args.nodes, args.edges, nnz, seeds.size, args.rho, args.epsilon,
                                "r" if world > 1 else "0", args.shards,
                                " + RCCL gather of %s on rank 0" % args.gather if world > 1 else ""),
+                "variant": args.variant,
                 "seeds_per_step": seeds_per_step,
                 "shards": args.shards,
                 "slots_per_gpu": info["slots"],
@@ -231,7 +239,10 @@ def main():
                 "algorithmic_bytes_per_launch": alg, "kernel_ms_per_launch": kernel_ms,
             },
         }
-        if world == 1 and args.cpu_seconds > 0:
+        if args.variant != "arcte":
+            # the 52/36/4/36-byte model prices ARCTE's push (s and r per edge); the PageRank flavours move less
+            result["roofline"]["note"] = "algorithmic-byte model is ARCTE's; indicative only for this flavour"
+        if world == 1 and args.cpu_seconds > 0 and args.variant == "arcte" and not args.float32:
             result["cpu_baseline"] = cpu_baseline(w, out_degree, in_degree, shard, args.rho, args.epsilon, args.cpu_seconds)
         else:
             result["cpu_baseline"] = None

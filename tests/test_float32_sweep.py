@@ -63,3 +63,30 @@ def test_float32_versus_float64_on_flickr_shaped_graph():
     assert jaccard >= 0.97
     assert same / seeds.size >= 0.75
     assert max(rel) <= 1e-5
+
+
+@pytest.mark.parametrize("variant", [_native.PAGERANK, _native.LAZY_PAGERANK])
+def test_float32_pagerank_flavours_stay_close_to_float64(variant):
+    from conftest import load_golden
+    g = load_golden("rmat2000")
+    w = g["w"]
+    seeds = g["all_seeds"]
+    rho = g["rho"] if variant == _native.PAGERANK else (g["rho"] * 0.5) / (1 - 0.5 * g["rho"])
+    with _native.Context(w.indptr, w.indices, w.data, g["out_degree"], g["in_degree"]) as ctx:
+        ctx.run_seeds(seeds, rho, g["epsilon"], variant=variant)
+        c64, r64 = ctx.fetch()
+        ctx.set_float32(True)
+        ctx.run_seeds(seeds, rho, g["epsilon"], variant=variant)
+        c32, r32 = ctx.fetch()
+        s64, q64, s32, q32 = np.zeros(g["n"]), np.zeros(g["n"]), np.zeros(g["n"]), np.zeros(g["n"])
+        ctx.similarity_slice(seeds[0], rho, 1e-4, s32, q32, variant=variant)
+        ctx.set_float32(False)
+        ctx.similarity_slice(seeds[0], rho, 1e-4, s64, q64, variant=variant)
+    inter = union = 0
+    for k in range(seeds.size):
+        a, b = set(r64[c64[k]:c64[k + 1]].tolist()), set(r32[c32[k]:c32[k + 1]].tolist())
+        inter += len(a & b)
+        union += len(a | b)
+    assert inter / max(union, 1) >= 0.97
+    both = (s64 != 0) & (s32 != 0)
+    assert both.sum() > 0 and np.median(np.abs(s32[both] - s64[both]) / s64[both]) <= 1e-5

@@ -288,3 +288,28 @@ def test_seed_without_out_neighbours_is_rejected_like_the_reference():
         ctx.run_seeds(np.array([2]), 0.1, 1e-5, use_effective_epsilon=False)    # raw epsilon needs no neighbours
         colptr, rows, nop = ctx.fetch(want_nop=True)
         assert nop.tolist() == [1] and rows.size == 0
+
+
+def test_degenerate_graphs_and_seed_lists():
+    """Ragged / tiny inputs: single node, all-isolated graph, duplicate and unsorted seeds, a seed list that
+    is not in degree order, more slots than seeds."""
+    one = sparse.csr_matrix((1, 1), dtype=np.float64)
+    w, od, idg = get_natural_random_walk_matrix(one)
+    assert arcte(one, 0.1, 1e-5, 1).toarray().tolist() == [[1.0, 0.0]]
+    iso = sparse.csr_matrix((5, 5), dtype=np.float64)
+    f = arcte(iso, 0.1, 1e-5, 1)
+    assert f.shape == (5, 10) and np.array_equal(f.toarray()[:, :5], np.eye(5)) and f[:, 5:].nnz == 0
+    g = load_golden("ba300")
+    seeds = np.array([7, 3, 250, 3, 7, 120, 0], dtype=np.int64)      # duplicates, unsorted
+    got = arcte_worker(seeds, g["w"].indices, g["w"].indptr, g["w"].data, g["out_degree"], g["in_degree"],
+                       g["rho"], g["epsilon"])
+    with ctx_of(g) as ctx:
+        ctx.run_seeds(seeds, g["rho"], g["epsilon"])
+        colptr, rows = ctx.fetch()
+    o_colptr, o_rows = oracle.worker(g["w"], g["out_degree"], g["in_degree"], seeds, g["rho"], g["epsilon"])
+    assert np.array_equal(colptr, o_colptr)
+    for k in range(seeds.size):
+        assert np.array_equal(np.sort(rows[colptr[k]:colptr[k + 1]]), o_rows[o_colptr[k]:o_colptr[k + 1]])
+    # duplicate seeds write the same column twice: COO -> CSR sums them, exactly like the reference's coo_matrix
+    want = oracle.worker_matrix(g["w"], g["out_degree"], g["in_degree"], seeds, g["rho"], g["epsilon"])
+    assert_same_sparse(got, want)
