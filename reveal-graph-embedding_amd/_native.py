@@ -33,6 +33,7 @@ SIGNATURES = {
     "arcte_hip_result_device_rows": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "arcte_hip_copy_result_rows_to_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "arcte_hip_run_stats": (C.c_int, [C.c_void_p, _i64p]),
+    "arcte_hip_run_counters": (C.c_int, [C.c_void_p, _i64p, C.c_int]),
     "arcte_hip_run_timing": (C.c_int, [C.c_void_p, _f64p]),
     "arcte_hip_similarity_slice": (C.c_int, [C.c_void_p, C.c_int64, C.c_double, C.c_double, _f64p, _f64p,
                                              C.POINTER(C.c_int64)]),
@@ -177,10 +178,10 @@ class Context:
         return colptr
 
     def stats(self):
-        s = np.zeros(6, dtype=np.int64)
-        _check(lib().arcte_hip_run_stats(self._h, s))
+        s = np.zeros(7, dtype=np.int64)
+        _check(lib().arcte_hip_run_counters(self._h, s, s.size))
         return dict(pushes=int(s[0]), edges=int(s[1]), enqueues=int(s[2]), support=int(s[3]),
-                    reruns=int(s[4]), launches=int(s[5]))
+                    reruns=int(s[4]), launches=int(s[5]), candidates=int(s[6]))
 
     def timing(self):
         t = np.zeros(4, dtype=np.float64)

@@ -1,4 +1,5 @@
 import time, sys, numpy as np
+sys.path.insert(0, ".")
 from reveal_graph_embedding_amd import _native
 from reveal_graph_embedding_amd.synthetic import rmat_graph
 from reveal_graph_embedding_amd.eps_randomwalk.transition import get_natural_random_walk_matrix
