@@ -96,6 +96,9 @@ def main():
     ap.add_argument("--gather", choices=["rows", "counts"], default="rows",
                     help="N>1: what rank 0 collects per step (rows = the full result)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="process-group backend; gloo (host-staged gather, ranks may share a GPU) is only for "
+                         "rehearsing the N>1 code path on a box with fewer GPUs than ranks")
     ap.add_argument("--variant", choices=["arcte", "pagerank", "lazy"], default="arcte",
                     help="push flavour (default: ARCTE's cumulative PageRank difference = the BASELINE metric)")
     ap.add_argument("--float32", action="store_true", help="float32 arithmetic (tolerance sweep only; not the metric)")
@@ -112,11 +115,19 @@ def main():
         raise SystemExit("--shards must be >= the number of GPUs")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    if args.backend == "nccl" and local_rank >= ndev:
+        raise SystemExit("rank %d has no GPU of its own (%d visible): RCCL needs one GPU per rank" % (rank, ndev))
+    gpu = local_rank % ndev
+    torch.cuda.set_device(gpu)
+    dev = torch.device("cuda", gpu)
+    comm_dev = dev if args.backend == "nccl" else torch.device("cpu")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     def barrier():
         if world > 1:
@@ -133,7 +144,7 @@ def main():
     shard = shard_seeds(seeds, args.shards, rank)
     nnz = int(adjacency.nnz)
     del adjacency
-    ctx = _native.Context(w.indptr, w.indices, w.data, out_degree, in_degree, device=local_rank, n_slots=args.slots)
+    ctx = _native.Context(w.indptr, w.indices, w.data, out_degree, in_degree, device=gpu, n_slots=args.slots)
     info = ctx.info()
     log("[bench] rank %d: n=%d nnz=%d seeds=%d shard=%d slots=%d device_bytes=%.1f GB" % (
         rank, args.nodes, nnz, seeds.size, shard.size, info["slots"], info["device_bytes"] / 1e9))
@@ -149,12 +160,13 @@ def main():
         ctx.run_seeds(shard, run_rho, args.epsilon, use_effective_epsilon=True, variant=variant)
         if world > 1:
             _, total = ctx.result_sizes()
-            counts_t = torch.from_numpy(np.diff(ctx.colptr())).to(dev)
+            counts_t = torch.from_numpy(np.diff(ctx.colptr())).to(comm_dev)
             if args.gather == "rows":
                 rows_t = torch.empty(total, dtype=torch.int32, device=dev)
                 ctx.copy_rows_to_device(rows_t.data_ptr(), total)
+                rows_t = rows_t.to(comm_dev)
             else:
-                rows_t = torch.empty(0, dtype=torch.int32, device=dev)
+                rows_t = torch.empty(0, dtype=torch.int32, device=comm_dev)
             out = gather_shards(counts_t, rows_t, dst=0)
             if out is not None:
                 gathered_rows = sum(int(r.numel()) for _, r in out)
@@ -172,10 +184,10 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-        nseeds_t = torch.tensor([shard.size], dtype=torch.int64, device=dev)
+        nseeds_t = torch.tensor([shard.size], dtype=torch.int64, device=comm_dev)
         dist.all_reduce(nseeds_t, op=dist.ReduceOp.SUM)
         seeds_per_step = int(nseeds_t.item())
     else:
@@ -219,7 +231,8 @@ def main():
                             "over the degree-descending seed list) per GPU through eps_eff -> eps-push -> extraction%s"
                             % (args.nodes, args.edges, nnz, seeds.size, args.rho, args.epsilon,
                                "r" if world > 1 else "0", args.shards,
-                               " + RCCL gather of %s on rank 0" % args.gather if world > 1 else ""),
+                               " + %s gather of %s on rank 0" % ("RCCL" if args.backend == "nccl" else "gloo (rehearsal)",
+                                                                  args.gather) if world > 1 else ""),
                 "variant": args.variant,
                 "seeds_per_step": seeds_per_step,
                 "shards": args.shards,

@@ -1,0 +1,689 @@
+// Device code of the ARCTE hot path for gfx950 (wave64): effective-epsilon kernel, the per-seed
+// propagation + extraction kernel (templated on mode, push flavour and value type) and the small
+// utility kernels.  Included by arcte_hip.hip only; see that file's header for the design.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+// ---------------------------------------------------------------------------------------------
+// device helpers (wave64)
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+constexpr int WAVE = 64;
+constexpr int WAVES_PER_BLOCK = 4;
+constexpr int BLOCK = WAVE * WAVES_PER_BLOCK;
+
+enum SeedStatus : int32_t {
+    ST_OK = 0,
+    ST_QUEUE_OVERFLOW = 1,
+    ST_OUTPUT_OVERFLOW = 2,
+    ST_MISSING_BASE = 3,
+    ST_RUNAWAY = 4,   // push cap hit: every wave must reach an exit (guards against a non-converging input)
+};
+
+__device__ __forceinline__ int lane_below(uint64_t m)
+{
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+}
+
+__device__ __forceinline__ uint64_t bcast_u64(uint64_t v)
+{
+    uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+    uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+
+
+__device__ __forceinline__ double shfl_f64(double v, int src) { return __shfl(v, src, WAVE); }
+__device__ __forceinline__ int64_t shfl_i64(int64_t v, int src)
+{
+    int lo = __shfl((int)(uint32_t)v, src, WAVE);
+    int hi = __shfl((int)(uint32_t)((uint64_t)v >> 32), src, WAVE);
+    return (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
+}
+
+__device__ __forceinline__ double wave_min(double x)
+{
+    for (int o = 32; o > 0; o >>= 1) {
+        double y = __shfl_xor(x, o, WAVE);
+        x = (y < x) ? y : x;
+    }
+    return x;
+}
+__device__ __forceinline__ double wave_max(double x)
+{
+    for (int o = 32; o > 0; o >>= 1) {
+        double y = __shfl_xor(x, o, WAVE);
+        x = (y > x) ? y : x;
+    }
+    return x;
+}
+
+struct GraphDev {
+    int64_t n;
+    const int64_t *indptr;
+    const int32_t *indices;
+    const double *data;
+    const double *out_degree;
+    const double *in_degree;
+    const double *edge_in_degree;   // in_degree[indices[k]] stored with the edge: streams with the row
+    const float *data_f, *in_degree_f, *edge_in_degree_f;   // float32 copies (NULL until float32 is switched on)
+};
+
+// ---------------------------------------------------------------------------------------------
+// a4: calculate_epsilon_effective (arcte.py:26-50), one wavefront per seed
+// ---------------------------------------------------------------------------------------------
+
+struct PwFrame {
+    int64_t lo;
+    int64_t n;
+    double left;
+    int32_t stage;
+    int32_t pad;
+};
+
+struct EpsShared {
+    double leaf[128];
+    PwFrame frames[40];
+};
+
+// numpy pairwise leaf (n <= 128) over a[i] = out_degree[indices[lo + i]]; also folds min/max of a.
+__device__ double pw_leaf(const GraphDev &g, int64_t lo, int64_t n, double *leaf, int lane, double &amin, double &amax)
+{
+    for (int i = lane; i < n; i += WAVE) {
+        double a = g.out_degree[g.indices[lo + i]];
+        leaf[i] = a;
+        amin = (a < amin) ? a : amin;
+        amax = (a > amax) ? a : amax;
+    }
+    // same-wave LDS write -> read: the DS queue is in order, the compiler keeps the dependency
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    double res;
+    if (n < 8) {
+        res = 0.0;
+        for (int i = 0; i < n; i++) res += leaf[i];
+    } else {
+        int64_t nfull = n - (n % 8);
+        double r = 0.0;
+        if (lane < 8) {
+            r = leaf[lane];
+            for (int64_t i = 8 + lane; i < nfull; i += 8) r += leaf[i];
+        }
+        double r0 = shfl_f64(r, 0), r1 = shfl_f64(r, 1), r2 = shfl_f64(r, 2), r3 = shfl_f64(r, 3);
+        double r4 = shfl_f64(r, 4), r5 = shfl_f64(r, 5), r6 = shfl_f64(r, 6), r7 = shfl_f64(r, 7);
+        res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+        for (int64_t i = nfull; i < n; i++) res += leaf[i];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    return res;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_epsilon_effective(GraphDev g, const int32_t *seeds, int64_t nseeds,
+                                                             double epsilon, double *eps_out)
+{
+    __shared__ EpsShared sh[WAVES_PER_BLOCK];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    EpsShared &S = sh[wave];
+    const int64_t k = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wave;
+    if (k >= nseeds) return;
+    const int32_t seed = seeds[k];
+    const int64_t b = g.indptr[seed];
+    const int64_t m = g.indptr[seed + 1] - b;
+    const double ds = g.out_degree[seed];
+    double amin = INFINITY, amax = -INFINITY;
+
+    // pairwise recursion of numpy's float64 add.reduce, evaluated with an explicit frame stack
+    int sp = 0;
+    double ret = 0.0;
+    if (lane == 0) { S.frames[0].lo = b; S.frames[0].n = m; S.frames[0].stage = 0; }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    while (sp >= 0) {
+        const int64_t flo = S.frames[sp].lo;
+        const int64_t fn = S.frames[sp].n;
+        const int stage = S.frames[sp].stage;
+        if (fn <= 128) {
+            ret = pw_leaf(g, flo, fn, S.leaf, lane, amin, amax);
+            sp--;
+            continue;
+        }
+        int64_t n2 = fn / 2;
+        n2 -= n2 % 8;
+        if (stage == 0) {
+            if (lane == 0) {
+                S.frames[sp].stage = 1;
+                S.frames[sp + 1].lo = flo; S.frames[sp + 1].n = n2; S.frames[sp + 1].stage = 0;
+            }
+            sp++;
+        } else if (stage == 1) {
+            if (lane == 0) {
+                S.frames[sp].left = ret;
+                S.frames[sp].stage = 2;
+                S.frames[sp + 1].lo = flo + n2; S.frames[sp + 1].n = fn - n2; S.frames[sp + 1].stage = 0;
+            }
+            sp++;
+        } else {
+            ret = S.frames[sp].left + ret;
+            sp--;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    }
+    amin = wave_min(amin);
+    amax = wave_max(amax);
+    if (lane == 0) {
+        double mean = ret / (double)m;                                            // arcte.py:32
+        double e = (epsilon * log(1 + ds)) / log(1 + mean);                       // :35
+        // :39-40  max/min over i of 1/(ds*a_i): correctly rounded * and / are monotone, so the
+        // extrema sit at the extrema of a_i
+        double emax = 1 / (ds * amin);
+        double emin = 1 / (ds * amax);
+        if (m == 0) { emax = -INFINITY; emin = INFINITY; }
+        if (e > emax) e = emax;                                                   // :45-48
+        else if (e < emin) e = (emin + e) / 2;
+        eps_out[k] = e;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// a2 + a3 + a5: per-seed FIFO propagation and community extraction
+// ---------------------------------------------------------------------------------------------
+
+// Dense per-slot state, one 32-byte sector per node.  An entry is live only while its epoch equals
+// the slot's current epoch (one epoch per seed), so "s[:] = 0; r[:] = 0" (arcte.py:337-338) costs
+// nothing and first touches are recognised without a separate bitmap.
+template <typename T> struct EntryT;
+template <> struct __attribute__((aligned(32))) EntryT<double> {
+    double r;
+    double s;
+    double d;         // in_degree of the node (threshold tests and the degree normalisation)
+    uint32_t epoch;
+    uint32_t pad;
+};
+// float32 flavour (BASELINE.json configs[4] tolerance sweep): one 16-byte entry per node
+template <> struct __attribute__((aligned(16))) EntryT<float> {
+    float r;
+    float s;
+    float d;
+    uint32_t epoch;
+};
+typedef EntryT<double> Entry;
+static_assert(sizeof(Entry) == 32, "Entry must be one 32-byte sector");
+static_assert(sizeof(EntryT<float>) == 16, "float entry must be 16 bytes");
+
+template <typename T> struct LoT { T r, s; };
+template <typename T> struct HiT { T d; uint32_t epoch; };
+
+__device__ __forceinline__ LoT<double> load_lo(const EntryT<double> *e) { double2 t = *reinterpret_cast<const double2 *>(e); return {t.x, t.y}; }
+__device__ __forceinline__ HiT<double> load_hi(const EntryT<double> *e)
+{
+    double2 t = *(reinterpret_cast<const double2 *>(e) + 1);
+    return {t.x, (uint32_t)(uint64_t)__double_as_longlong(t.y)};
+}
+__device__ __forceinline__ void store_lo(EntryT<double> *e, double r, double s) { *reinterpret_cast<double2 *>(e) = make_double2(r, s); }
+__device__ __forceinline__ void store_hi(EntryT<double> *e, double d, uint32_t epoch)
+{
+    *(reinterpret_cast<double2 *>(e) + 1) = make_double2(d, __longlong_as_double((long long)(uint64_t)epoch));
+}
+__device__ __forceinline__ LoT<float> load_lo(const EntryT<float> *e) { float2 t = *reinterpret_cast<const float2 *>(e); return {t.x, t.y}; }
+__device__ __forceinline__ HiT<float> load_hi(const EntryT<float> *e)
+{
+    float2 t = *(reinterpret_cast<const float2 *>(e) + 1);
+    return {t.x, __float_as_uint(t.y)};
+}
+__device__ __forceinline__ void store_lo(EntryT<float> *e, float r, float s) { *reinterpret_cast<float2 *>(e) = make_float2(r, s); }
+__device__ __forceinline__ void store_hi(EntryT<float> *e, float d, uint32_t epoch)
+{
+    *(reinterpret_cast<float2 *>(e) + 1) = make_float2(d, __uint_as_float(epoch));
+}
+
+// the float64 / float32 views of the graph's value arrays
+template <typename T> struct GraphValues { const T *data, *in_degree, *edge_in_degree; };
+template <typename T> __device__ __forceinline__ GraphValues<T> graph_values(const GraphDev &g);
+template <> __device__ __forceinline__ GraphValues<double> graph_values<double>(const GraphDev &g) { return {g.data, g.in_degree, g.edge_in_degree}; }
+template <> __device__ __forceinline__ GraphValues<float> graph_values<float>(const GraphDev &g) { return {g.data_f, g.in_degree_f, g.edge_in_degree_f}; }
+
+template <typename T> __device__ __forceinline__ T shfl_real(T v, int src);
+template <> __device__ __forceinline__ double shfl_real<double>(double v, int src) { return shfl_f64(v, src); }
+template <> __device__ __forceinline__ float shfl_real<float>(float v, int src) { return __shfl(v, src, WAVE); }
+template <typename T> __device__ __forceinline__ T wave_min_real(T x)
+{
+    for (int o = 32; o > 0; o >>= 1) {
+        T y = __shfl_xor(x, o, WAVE);
+        x = (y < x) ? y : x;
+    }
+    return x;
+}
+// margin of the candidate bound: far above one rounding error of the type, far below any real gap
+template <typename T> __device__ __forceinline__ T cand_margin();
+template <> __device__ __forceinline__ double cand_margin<double>() { return 1.0 - 0x1p-40; }
+template <> __device__ __forceinline__ float cand_margin<float>() { return 1.0f - 0x1p-16f; }
+
+struct PushParams {
+    GraphDev g;
+    // work list
+    const int32_t *work_pos;   // positions into seeds/eps/out arrays for this launch (NULL = identity)
+    int64_t nwork;
+    unsigned long long *work_counter;
+    const int32_t *seeds;
+    const double *eps;
+    double one_minus_rho;
+    double rho;        // PageRank flavours: s[u] += rho*r[u]
+    double lazy;       // lazy flavour: laziness factor
+    // per-slot scratch
+    void *state;       // [slots][n] EntryT<T>
+    uint32_t *slot_epoch;   // [slots] last epoch used by the slot
+    int32_t *queue;    // [slots][qcap]
+    int32_t *sup;      // [slots][n]   candidate list (see cand_thr)
+    uint32_t qcap;     // power of two
+    int32_t max_pushes; // per-seed cap, see ST_RUNAWAY
+    int32_t refresh_failing_only;   // pop-batch refresh policy (both exact)
+    // outputs
+    int32_t *raw;      // raw row arena, allocation order
+    unsigned long long rawcap;
+    unsigned long long *raw_cursor;
+    int64_t *out_off;
+    int32_t *out_cnt;
+    int32_t *status;
+    int32_t *nop;
+    unsigned long long *stats;   // [0] pushes [1] edges [2] enqueues [3] support [4] failed seeds [5] candidates
+};
+
+// MODE 0: full arcte_worker body (extract).  MODE 1: similarity slice only on the dense vectors the
+// host placed in slot 0 (k_state_from_dense), left there for k_state_to_dense.
+// VAR 0: cumulative PageRank difference (push.py:41-64, similarity.py:149-222) -- ARCTE proper.
+// VAR 1: PageRank limit push (push.py:4-17, similarity.py:11-63).
+// VAR 2: lazy PageRank push (push.py:20-38, similarity.py:66-146) with its self re-push loops.
+template <int MODE, int VAR, typename T>
+__global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int64_t slot = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wave;
+    const GraphDev &g = P.g;
+    const GraphValues<T> gv = graph_values<T>(g);
+    EntryT<T> *__restrict__ st = reinterpret_cast<EntryT<T> *>(P.state) + slot * g.n;
+    int32_t *__restrict__ q = P.queue + slot * (int64_t)P.qcap;
+    int32_t *__restrict__ sup = P.sup + slot * g.n;
+    const uint32_t qmask = P.qcap - 1;
+    const T omr = (T)P.one_minus_rho;
+    uint32_t epoch = P.slot_epoch[slot];
+
+    // Dynamic seed queue: lane 0 draws the next work item, the wave broadcasts it.  The
+    // wave_barrier (convergent, emits nothing) keeps LLVM's jump threading from fusing this
+    // lane-0 block with the lane-0 block that ends the previous iteration -- that fusion turned the
+    // loop divergent (lanes 1..63 ran ahead without lane 0 and never left it).
+    auto next_work = [&]() -> unsigned long long {
+        __builtin_amdgcn_wave_barrier();
+        unsigned long long w = 0;
+        if (lane == 0) w = atomicAdd(P.work_counter, 1ULL);
+        return bcast_u64(w);
+    };
+    for (unsigned long long wk = next_work(); wk < (unsigned long long)P.nwork; wk = next_work()) {
+        const int32_t pos = P.work_pos ? P.work_pos[wk] : (int32_t)wk;
+        const int32_t seed = P.seeds[pos];
+        const T eps = (T)P.eps[pos];
+        if (MODE == 0) {
+            // the arena is already full: this seed is re-run by the host after the arena is drained
+            unsigned long long cur = 0;
+            if (lane == 0) cur = __hip_atomic_load(P.raw_cursor, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            cur = bcast_u64(cur);
+            if (cur > P.rawcap) {
+                if (lane == 0) {
+                    P.status[pos] = ST_OUTPUT_OVERFLOW;
+                    P.out_cnt[pos] = 0;
+                    P.out_off[pos] = 0;
+                    P.nop[pos] = 0;
+                    atomicAdd(&P.stats[4], 1ULL);
+                }
+                continue;
+            }
+        }
+        epoch++;                           // every entry of the previous seed is stale from here on
+
+        uint32_t head = 0, tail = 0;       // ring counters (wave-uniform)
+        int32_t nsup = 0;          // candidates
+        int32_t nfirst = 0;        // nodes with s != 0 (the support of the similarity slice)
+        T cand_thr = T(0);
+        int32_t npush = 0;
+        unsigned long long nedges = 0;
+        bool ok = true, runaway = false;
+
+        // ---- one push of node u (push.py:41-64) followed by the ordered enqueue of
+        //      similarity.py:194-196 / :214-216.  `ru` is r[u] at pop time.
+        auto push = [&](int32_t u, T ru, int64_t rb, int64_t re, bool do_enqueue) {
+            T c;            // what every neighbour receives per unit of transition weight
+            T r_self;       // r[u] right after the push bookkeeping (what a self-loop lane adds to)
+            if (VAR == 0) {
+                c = omr * ru;                                    // push.py:56
+                r_self = T(0);
+                if (lane == 0) st[u].r = T(0);                    // push.py:59
+            } else {
+                const T A = (T)P.rho * ru;                     // push.py:10 / :29
+                if (VAR == 1) { c = omr * ru; r_self = T(0); }                                  // push.py:11,15
+                else { c = omr * (1 - (T)P.lazy) * ru; r_self = omr * (T)P.lazy * (ru); }            // push.py:30-31
+                bool grew = false;
+                if (lane == 0) {
+                    const T s_old = st[u].s;                // u is live: it was deposited to, or is the seed
+                    const T s_new = s_old + A;              // push.py:14 / :34
+                    store_lo(st + u, r_self, s_new);             // push.py:15 / :35
+                    grew = s_old == T(0) && s_new != T(0);
+                    if (grew) sup[nsup] = u;                     // s is non-zero exactly at pushed nodes
+                }
+                const int g1 = __popcll(__ballot(grew));
+                nsup += g1;
+                nfirst += g1;
+            }
+            for (int64_t base = rb; base < re; base += 2 * WAVE) {
+                const int64_t k0 = base + lane, k1 = k0 + WAVE;
+                const bool a0 = k0 < re, a1 = k1 < re;
+                int32_t v0 = 0, v1 = 0;
+                T w0 = T(0), w1 = T(0), d0 = T(1), d1 = T(1);
+                if (a0) { v0 = g.indices[k0]; w0 = gv.data[k0]; d0 = gv.edge_in_degree[k0]; }
+                if (a1) { v1 = g.indices[k1]; w1 = gv.data[k1]; d1 = gv.edge_in_degree[k1]; }
+                LoT<T> l0 = {T(0), T(0)}, l1 = {T(0), T(0)};
+                HiT<T> h0 = {T(1), 0u}, h1 = {T(1), 0u};
+                if (a0) { l0 = load_lo(st + v0); h0 = load_hi(st + v0); }
+                if (a1) { l1 = load_lo(st + v1); h1 = load_hi(st + v1); }
+#pragma unroll
+                for (int t = 0; t < 2; t++) {
+                    const bool act = t ? a1 : a0;
+                    const int32_t v = t ? v1 : v0;
+                    const T w = t ? w1 : w0;
+                    const T dv = t ? d1 : d0;
+                    const LoT<T> lo = t ? l1 : l0;
+                    const bool live = (t ? h1.epoch : h0.epoch) == epoch;
+                    const T p = c * w;                                  // push.py:62 / :17 / :38
+                    const T r_old = live ? ((v != u) ? lo.r : r_self) : T(0);   // a self-loop sees r[u] as just set
+                    const T s_old = live ? lo.s : T(0);
+                    const T r_new = r_old + p;                          // push.py:64
+                    const T s_new = (VAR == 0) ? s_old + p : s_old;     // push.py:63 (ARCTE only)
+                    if (act) {
+                        store_lo(st + v, r_new, s_new);
+                        if (!live) store_hi(st + v, dv, epoch);
+                    }
+                    if (VAR == 0) {
+                        // Candidate list: every node whose s/in_degree has reached cand_thr, a lower bound of
+                        // the final selection threshold (s only grows, so each node crosses once).  It replaces
+                        // the full touched list: extraction only has to look at candidates.
+                        const T bar = cand_thr * dv;
+                        const bool cross = act && (s_new > T(0) && s_new >= bar) && !(s_old > T(0) && s_old >= bar);
+                        const uint64_t mc = __ballot(cross);
+                        if (cross) sup[nsup + lane_below(mc)] = v;
+                        nsup += __popcll(mc);
+                        nfirst += __popcll(__ballot(act && s_old == T(0) && s_new != T(0)));   // support of s grows
+                    }
+                    if (!do_enqueue) continue;
+                    const bool enq = act && (r_new / dv >= eps);             // similarity.py:194/214
+                    const uint64_t me = __ballot(enq);
+                    const uint32_t cnt = __popcll(me);
+                    if (cnt) {
+                        if (tail - head + cnt > P.qcap) { ok = false; }
+                        else {
+                            if (enq) q[(tail + lane_below(me)) & qmask] = v;
+                            tail += cnt;
+                        }
+                    }
+                }
+                if (!ok) break;
+            }
+            npush++;
+            nedges += (unsigned long long)(re - rb);
+            if (npush >= P.max_pushes) { ok = false; runaway = true; }
+        };
+
+        // ---- similarity.py:176-192: s[seed] = r[seed] = 1, one unconditional push
+        const int64_t seed_b = g.indptr[seed], seed_e = g.indptr[seed + 1];
+        const T seed_d = gv.in_degree[seed];
+        if (lane == 0) {
+            if (VAR == 0) store_lo(st + seed, T(1), T(1));         // similarity.py:176-177
+            else if (MODE == 0) store_lo(st + seed, T(1), T(0));   // similarity.py:26 / :85: only r[seed] = 1
+            else st[seed].r = T(1);                                //   (MODE 1: the caller's s[seed] stays)
+            if (MODE == 0) store_hi(st + seed, seed_d, epoch);   // MODE 1: the host made every entry live
+            if (VAR == 0) sup[0] = seed;
+        }
+        nsup = (VAR == 0) ? 1 : 0;
+        nfirst = (VAR == 0) ? 1 : 0;
+        if (MODE == 0 && VAR == 0) {
+            // Lower bound of the selection threshold (arcte.py:358-360): the threshold is the minimum of
+            // s/in_degree over the closed neighbourhood at the END; s never decreases, so the minimum
+            // right after the first push (s[b] = c*w_b, s[seed] >= 1) bounds it from below.  Scaled down a
+            // hair so that the cheap product test s >= cand_thr*d admits everything the exact division does.
+            T lb = T(1) / seed_d;
+            const T c0 = omr * T(1);
+            for (int64_t k = seed_b + lane; k < seed_e; k += WAVE) {
+                const T x = (c0 * gv.data[k]) / gv.edge_in_degree[k];
+                lb = (x < lb) ? x : lb;
+            }
+            cand_thr = wave_min_real<T>(lb) * cand_margin<T>();
+        }
+        // (PageRank flavours: s is non-zero only at pushed nodes; the candidate list is the pushed nodes)
+        push(seed, T(1), seed_b, seed_e, true);
+        if (VAR == 2) {
+            // similarity.py:108-116: re-push the seed while it stays above the threshold, no enqueue
+            while (ok) {
+                const T ru2 = st[seed].r;
+                if (!(ru2 / seed_d >= eps)) break;
+                push(seed, ru2, seed_b, seed_e, false);
+            }
+        }
+
+        // ---- similarity.py:199-216: FIFO with duplicates.  Up to 64 queue entries are taken per
+        //      batch; r/in_degree of all of them is tested in parallel and the first passing entry
+        //      (in FIFO order) is pushed; entries before it are no-op pops.  r of the not yet
+        //      consumed entries is re-read after every push, so every test sees r at its pop time.
+        while (ok && head != tail) {
+            const uint32_t navail = tail - head;
+            const uint32_t bn = navail < (uint32_t)WAVE ? navail : (uint32_t)WAVE;
+            const bool valid = (uint32_t)lane < bn;
+            int32_t u_l = 0;
+            T r_l = T(0), d_l = T(1);
+            int64_t rb_l = 0, re_l = 0;
+            if (valid) {
+                u_l = q[(head + lane) & qmask];
+                r_l = st[u_l].r;              // queued nodes were deposited to in this epoch: live
+                d_l = st[u_l].d;
+                rb_l = g.indptr[u_l];
+                re_l = g.indptr[u_l + 1];
+            }
+            head += bn;    // the batch lives in registers from here on
+            int consumed = 0;
+            bool pass = valid && (r_l / d_l >= eps);                                  // similarity.py:204
+            for (;;) {
+                const uint64_t m = __ballot(pass && lane >= consumed);
+                if (m == 0) break;
+                const int i = __ffsll((unsigned long long)m) - 1;
+                const int32_t u = __shfl(u_l, i, WAVE);
+                const T du = shfl_real<T>(d_l, i);
+                T ru = shfl_real<T>(r_l, i);
+                consumed = i + 1;
+                if (P.refresh_failing_only) {
+                    // r of a passing entry can only have grown since it was read -- unless the node was pushed in
+                    // between (the queue holds duplicates): read it again, it is this entry's pop time now
+                    ru = st[u].r;
+                    if (!(ru / du >= eps)) {
+                        if (lane == i) pass = false;
+                        continue;
+                    }
+                }
+                const int64_t rb = shfl_i64(rb_l, i);
+                const int64_t re = shfl_i64(re_l, i);
+                push(u, ru, rb, re, true);
+                if (VAR == 2) {
+                    // similarity.py:136-144: re-push the same node while it stays above the threshold
+                    while (ok) {
+                        const T ru2 = st[u].r;
+                        if (!(ru2 / du >= eps)) break;
+                        push(u, ru2, rb, re, false);
+                    }
+                }
+                if (!ok) break;
+                // re-test the entries not consumed yet: all of them (every test then sees r at its pop time), or
+                // only those that did not pass (a passing entry is re-read when its turn comes)
+                if (valid && lane >= consumed && !(P.refresh_failing_only && pass)) {
+                    r_l = st[u_l].r;
+                    pass = r_l / d_l >= eps;
+                }
+            }
+        }
+
+        // ---- arcte.py:352-376: degree-normalise, threshold = min over the closed neighbourhood,
+        //      select everything at or above it, emit iff larger than the base community.
+        //      One pass over the candidate list: selected nodes are compacted in place, then copied.
+        int32_t sta = ok ? ST_OK : (runaway ? ST_RUNAWAY : ST_QUEUE_OVERFLOW);
+        int32_t emitted = 0, support = 0;
+        const int32_t ncand = nsup;
+        unsigned long long off = 0;
+        if (MODE == 0 && ok) {
+            const int64_t sb = g.indptr[seed], se = g.indptr[seed + 1];
+            T thr = st[seed].s / st[seed].d;
+            bool miss = st[seed].s == T(0), selfloop = false;
+            for (int64_t k = sb + lane; k < se; k += WAVE) {
+                const int32_t v = g.indices[k];
+                selfloop |= (v == seed);
+                const LoT<T> lo = load_lo(st + v);
+                const HiT<T> hi = load_hi(st + v);
+                const T sv = (hi.epoch == epoch) ? lo.s : T(0);
+                miss |= (sv == T(0));
+                const T x = sv / gv.edge_in_degree[k];
+                thr = (x < thr) ? x : thr;
+            }
+            thr = wave_min_real<T>(thr);
+            const bool missing = __ballot(miss) != 0;
+            if (VAR == 0 && missing) sta = ST_MISSING_BASE;
+            else if (VAR != 0 && (missing || __ballot(selfloop) != 0)) {
+                // arcte.py:129-133: the PageRank flavours skip a seed whose closed neighbourhood is not inside
+                // the support; intersect1d de-duplicates, so a seed with a self-loop never passes the guard
+                support = nfirst;
+            } else {
+                int32_t cnt = 0;
+                for (int32_t i0 = 0; i0 < nsup; i0 += WAVE) {
+                    const int32_t i = i0 + lane;
+                    bool sel = false;
+                    int32_t v = 0;
+                    if (i < nsup) {
+                        v = sup[i];
+                        sel = (st[v].s / st[v].d) >= thr;                 // arcte.py:363-367
+                    }
+                    const uint64_t ms = __ballot(sel);
+                    if (sel) sup[cnt + lane_below(ms)] = v;               // in place: cnt <= i0
+                    cnt += __popcll(ms);
+                }
+                support = nfirst;
+                if ((int64_t)cnt > (se - sb) + 1) {                                   // arcte.py:370
+                    if (lane == 0) off = atomicAdd(P.raw_cursor, (unsigned long long)cnt);
+                    off = bcast_u64(off);
+                    if (off + (unsigned long long)cnt > P.rawcap) sta = ST_OUTPUT_OVERFLOW;
+                    else {
+                        for (int32_t i = lane; i < cnt; i += WAVE) P.raw[off + i] = sup[i];
+                        emitted = cnt;
+                    }
+                }
+            }
+        }
+        if (lane == 0) {
+            P.status[pos] = sta;
+            P.out_cnt[pos] = emitted;
+            P.out_off[pos] = (int64_t)off;
+            P.nop[pos] = npush;
+            if (sta == ST_OK) {
+                atomicAdd(&P.stats[0], (unsigned long long)npush);
+                atomicAdd(&P.stats[1], nedges);
+                atomicAdd(&P.stats[2], (unsigned long long)tail);
+                atomicAdd(&P.stats[3], (unsigned long long)support);
+                atomicAdd(&P.stats[5], (unsigned long long)ncand);
+            } else {
+                atomicAdd(&P.stats[4], 1ULL);
+            }
+        }
+    }
+    if (lane == 0) P.slot_epoch[slot] = epoch;
+}
+
+// copy per-seed segments src[src_off[p] .. +cnt[p]) -> dst[dst_off[p] ..), one wavefront per segment;
+// p = work_pos[k] (identity when NULL)
+__global__ __launch_bounds__(BLOCK) void k_gather_segments(const int32_t *src, const int64_t *src_off, const int32_t *cnt,
+                                                           const int64_t *dst_off, int32_t *dst, const int32_t *work_pos,
+                                                           int64_t nseg)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t k = (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (k >= nseg) return;
+    const int64_t p = work_pos ? work_pos[k] : k;
+    const int32_t c = cnt[p];
+    const int32_t *s = src + src_off[p];
+    int32_t *d = dst + dst_off[p];
+    for (int32_t i = lane; i < c; i += WAVE) d[i] = s[i];
+}
+
+// caller's dense s, r -> slot 0, every entry live in the epoch the slice kernel is about to use
+template <typename T>
+__global__ void k_state_from_dense(const double *s, const double *r, const double *in_degree, void *state,
+                                   const uint32_t *slot_epoch, int64_t n)
+{
+    EntryT<T> *st = reinterpret_cast<EntryT<T> *>(state);
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        store_lo(st + i, (T)r[i], (T)s[i]);
+        store_hi(st + i, (T)in_degree[i], slot_epoch[0] + 1);
+    }
+}
+
+// slot 0 -> dense s, r (slot_epoch[0] is the epoch the slice kernel just used)
+template <typename T>
+__global__ void k_state_to_dense(const void *state, const uint32_t *slot_epoch, double *s, double *r, int64_t n)
+{
+    const EntryT<T> *st = reinterpret_cast<const EntryT<T> *>(state);
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const LoT<T> lo = load_lo(st + i);
+        const bool live = load_hi(st + i).epoch == slot_epoch[0];
+        r[i] = live ? (double)lo.r : 0.0;
+        s[i] = live ? (double)lo.s : 0.0;
+    }
+}
+
+__global__ void k_to_float(const double *in, float *out, int64_t n)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (float)in[i];
+}
+
+// in_degree[indices[k]] for every stored edge
+__global__ void k_edge_in_degree(const int32_t *indices, const double *in_degree, double *out, int64_t nnz)
+{
+    int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < nnz) out[k] = in_degree[indices[k]];
+}
+
+// push.py:41-64 (variant 0), :4-17 (variant 1), :20-38 (variant 2) on dense device vectors, one workgroup
+__global__ __launch_bounds__(BLOCK) void k_single_push(double *s, double *r, const double *w_i, const int32_t *a_i,
+                                                       int64_t deg, int64_t push_node, double rho, double one_minus_rho,
+                                                       int variant, double lazy)
+{
+    __shared__ double commute;
+    if (threadIdx.x == 0) {
+        const double ru = r[push_node];
+        if (variant == 0) {
+            commute = one_minus_rho * ru;
+            r[push_node] = 0.0;
+        } else {
+            s[push_node] += rho * ru;
+            if (variant == 1) { commute = one_minus_rho * ru; r[push_node] = 0.0; }
+            else { commute = one_minus_rho * (1 - lazy) * ru; r[push_node] = one_minus_rho * lazy * (ru); }
+        }
+    }
+    __syncthreads();
+    __threadfence_block();
+    const double c = commute;
+    for (int64_t k = threadIdx.x; k < deg; k += BLOCK) {
+        const int32_t v = a_i[k];
+        const double p = c * w_i[k];
+        if (variant == 0) s[v] += p;
+        r[v] += p;
+    }
+}
+
+}  // namespace

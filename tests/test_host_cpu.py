@@ -55,7 +55,7 @@ def test_product_does_not_import_oracle():
     pkg = os.path.join(ROOT, "reveal-graph-embedding_amd")
     for base, _, files in os.walk(pkg):
         for f in files:
-            if f.endswith((".py", ".hip", ".h", ".cpp")):
+            if f.endswith((".py", ".hip", ".h", ".hpp", ".cpp")):
                 text = open(os.path.join(base, f)).read()
                 for needle in ("import oracle", "from oracle", "liboracle", "oracle/", "oracle."):
                     assert needle not in text, (needle, os.path.join(base, f))
