@@ -112,13 +112,20 @@ def arcte_distributed(adjacency_matrix, rho, epsilon, device=None, group=None, r
         from reveal_graph_embedding_amd import _native
         if device is None:
             device = int(os.environ.get("LOCAL_RANK", "0"))
-        torch.cuda.set_device(device)
+        on_gpu = dist.get_backend(group) == "nccl"       # RCCL moves device memory; gloo needs host tensors
+        if on_gpu:
+            torch.cuda.set_device(device)
         with _native.Context(w.indptr, w.indices, w.data, out_degree, in_degree, device=device) as ctx:
             ctx.run_seeds(mine, rho, epsilon, use_effective_epsilon=True)
             _, total = ctx.result_sizes()
-            counts_t = torch.from_numpy(np.diff(ctx.colptr())).to("cuda:%d" % device)
-            rows_t = torch.empty(total, dtype=torch.int32, device="cuda:%d" % device)
-            ctx.copy_rows_to_device(rows_t.data_ptr(), total)
+            if on_gpu:
+                counts_t = torch.from_numpy(np.diff(ctx.colptr())).to("cuda:%d" % device)
+                rows_t = torch.empty(total, dtype=torch.int32, device="cuda:%d" % device)
+                ctx.copy_rows_to_device(rows_t.data_ptr(), total)
+            else:
+                colptr, rows = ctx.fetch()
+                counts_t = torch.from_numpy(np.diff(colptr))
+                rows_t = torch.from_numpy(rows)
     gathered = gather_shards(counts_t, rows_t, dst=0, group=group)
     if rank != 0:
         return None

@@ -62,3 +62,30 @@ def test_shard_seeds_is_the_reference_round_robin():
         chunks = list(parallel_chunks(seeds, world))
         for k in range(world):
             assert shard_seeds(seeds, world, k).tolist() == (chunks[k] or [])
+
+
+def _hip_worker(rank, world, port, name, out_path):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from reveal_graph_embedding_amd.distributed import arcte_distributed
+    g = load_golden(name)
+    f = arcte_distributed(g["adjacency"], g["rho"], g["epsilon"], device=0)     # both ranks share GPU 0
+    if rank == 0:
+        f.sort_indices()
+        np.savez(out_path, indptr=f.indptr, indices=f.indices, data=f.data, shape=np.array(f.shape))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_sharded_arcte_with_hip_compute_and_gloo_transport(tmp_path):
+    """Two ranks, HIP compute on the one GPU, host-staged gather: everything of the N>1 path except RCCL."""
+    import scipy.sparse as sparse
+    out = str(tmp_path / "f.npz")
+    mp.spawn(_hip_worker, args=(2, _free_port(), "rmat2000", out), nprocs=2, join=True)
+    z = np.load(out)
+    f = sparse.csr_matrix((z["data"], z["indices"], z["indptr"]), shape=tuple(z["shape"]))
+    assert_same_sparse(f, load_golden("rmat2000")["feat1"])
