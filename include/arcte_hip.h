@@ -108,6 +108,19 @@ int arcte_hip_result_sizes(arcte_hip_ctx *ctx, int64_t *nseeds, int64_t *total_r
 int arcte_hip_fetch_result(arcte_hip_ctx *ctx, int64_t *colptr, int32_t *rows,
                            double *eps_used, int64_t *nop);
 
+/*
+ * The last run as a ROW-compressed matrix, assembled on the device (64-bit key sort): row = node id, column =
+ * seed id, columns ascending inside a row -- the CSR that arcte_worker returns (arcte.py:379-388).  With
+ * with_base_block = 1 the columns are shifted by n and the base-community block I + pattern(W) of
+ * arcte.py:676-679 is merged in front, i.e. the result is arcte()'s n x 2n feature pattern (arcte.py:683); a
+ * node with a self-loop gets ONE diagonal entry there (the caller stores 2.0 for it, as the reference's I + ones
+ * does).  Call arcte_hip_result_csr_size first; indptr has n+1 entries, indices at least that many entries;
+ * *nnz_out receives the number of stored entries.  Seeds must be unique for a valid CSR.
+ */
+int arcte_hip_result_csr_size(arcte_hip_ctx *ctx, int with_base_block, int64_t *nnz);
+int arcte_hip_fetch_result_csr(arcte_hip_ctx *ctx, int with_base_block, int64_t *indptr, int32_t *indices,
+                               int64_t *nnz_out);
+
 /* Device addresses of the last run's rows (int32[total_rows]) for a device-side gather
  * (RCCL); valid until the next run on this context. */
 int arcte_hip_result_device_rows(arcte_hip_ctx *ctx, void **rows_dev);

@@ -30,6 +30,8 @@ SIGNATURES = {
                                               C.c_double]),
     "arcte_hip_result_sizes": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "arcte_hip_fetch_result": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "arcte_hip_result_csr_size": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int64)]),
+    "arcte_hip_fetch_result_csr": (C.c_int, [C.c_void_p, C.c_int, _i64p, C.c_void_p, C.POINTER(C.c_int64)]),
     "arcte_hip_result_device_rows": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "arcte_hip_copy_result_rows_to_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "arcte_hip_run_stats": (C.c_int, [C.c_void_p, _i64p]),
@@ -161,6 +163,18 @@ class Context:
         if want_nop:
             out.append(nop)
         return tuple(out)
+
+    def fetch_csr(self, with_base_block=False):
+        """The last run as CSR (indptr int64[n+1], indices int32), assembled on the device.  With the base block
+        the columns are those of arcte()'s n x 2n matrix.  Seeds must have been unique."""
+        nnz = C.c_int64(0)
+        _check(lib().arcte_hip_result_csr_size(self._h, 1 if with_base_block else 0, C.byref(nnz)))
+        indptr = np.zeros(self.n + 1, dtype=np.int64)
+        indices = np.zeros(max(nnz.value, 1), dtype=np.int32)
+        got = C.c_int64(0)
+        _check(lib().arcte_hip_fetch_result_csr(self._h, 1 if with_base_block else 0, indptr, indices.ctypes.data,
+                                                C.byref(got)))
+        return indptr, indices[:got.value]
 
     def result_device_rows(self):
         p = C.c_void_p()

@@ -17,6 +17,7 @@
 //
 // C ABI: include/arcte_hip.h.  No CPU fallback lives here.
 #include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
 
 #include <algorithm>
 #include <chrono>
@@ -259,7 +260,7 @@ int launch_seeds(arcte_hip_ctx *c, const PushParams &P, int64_t nwork, int varia
 
 extern "C" {
 
-int arcte_hip_abi_version(void) { return 4; }
+int arcte_hip_abi_version(void) { return 5; }
 
 const char *arcte_hip_last_error(void) { return g_err.c_str(); }
 
@@ -678,6 +679,66 @@ int arcte_hip_fetch_result(arcte_hip_ctx *c, int64_t *colptr, int32_t *rows, dou
         for (int64_t k = 0; k < ns; k++) nop[k] = tmp[k];
     }
     return 0;
+}
+
+int arcte_hip_result_csr_size(arcte_hip_ctx *c, int with_base_block, int64_t *nnz)
+{
+    if (!c || !nnz) return fail(ARCTE_HIP_EINVAL, "bad argument");
+    if (c->run_nseeds < 0) return fail(ARCTE_HIP_ESTATE, "no completed run on this context");
+    *nnz = c->final_rows + (with_base_block ? c->nnz + c->n : 0);
+    return 0;
+}
+
+int arcte_hip_fetch_result_csr(arcte_hip_ctx *c, int with_base_block, int64_t *indptr, int32_t *indices, int64_t *nnz_out)
+{
+    if (!c || !indptr || !nnz_out) return fail(ARCTE_HIP_EINVAL, "bad argument");
+    if (c->run_nseeds < 0) return fail(ARCTE_HIP_ESTATE, "no completed run on this context");
+    HIP_TRY(hipSetDevice(c->device));
+    const int64_t n = c->n, ns = c->run_nseeds;
+    const int64_t nbase = with_base_block ? c->nnz + n : 0;
+    const int64_t nkeys = nbase + c->final_rows;
+    if (nkeys >= ((int64_t)1 << 31)) return fail(ARCTE_HIP_ECAPACITY, "more than 2^31 entries: assemble on the host instead");
+    if (nkeys && !indices) return fail(ARCTE_HIP_EINVAL, "indices is NULL");
+    DevBuf<uint64_t> keys_a, keys_b;
+    DevBuf<int64_t> colptr_d, indptr_d;
+    DevBuf<int32_t> indices_d;
+    DevBuf<char> temp;
+    int rc = [&]() -> int {
+        HIP_TRY(keys_a.alloc(nkeys));
+        HIP_TRY(keys_b.alloc(nkeys));
+        HIP_TRY(indptr_d.alloc(n + 1));
+        HIP_TRY(indices_d.alloc(nkeys));
+        HIP_TRY(colptr_d.alloc(ns + 1));
+        HIP_TRY(hipMemcpyAsync(colptr_d.p, c->colptr.data(), (ns + 1) * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
+        if (with_base_block) {
+            int blocks = (int)((n + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
+            hipLaunchKernelGGL(k_keys_base, dim3(blocks), dim3(BLOCK), 0, c->stream, c->indptr.p, c->indices.p, n, keys_a.p);
+        }
+        if (ns && c->final_rows) {
+            int blocks = (int)((ns + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
+            hipLaunchKernelGGL(k_keys_local, dim3(blocks), dim3(BLOCK), 0, c->stream, c->rows_final.p, colptr_d.p, c->seeds_d.p, ns,
+                               with_base_block ? (uint32_t)n : 0u, keys_a.p + nbase);
+        }
+        HIP_TRY(hipGetLastError());
+        const int end_bit = 64;   // dropped identity entries carry all-ones keys and must sort last
+        size_t temp_bytes = 0;
+        HIP_TRY(hipcub::DeviceRadixSort::SortKeys(nullptr, temp_bytes, keys_a.p, keys_b.p, (int)nkeys, 0, end_bit, c->stream));
+        HIP_TRY(temp.alloc(temp_bytes));
+        if (nkeys) HIP_TRY(hipcub::DeviceRadixSort::SortKeys(temp.p, temp_bytes, keys_a.p, keys_b.p, (int)nkeys, 0, end_bit, c->stream));
+        const int tb = 256;
+        const int64_t work = std::max<int64_t>(nkeys, n + 1);
+        hipLaunchKernelGGL(k_keys_to_csr, dim3((unsigned)((work + tb - 1) / tb)), dim3(tb), 0, c->stream, keys_b.p, nkeys, n,
+                           indices_d.p, indptr_d.p);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipMemcpy(indptr, indptr_d.p, (n + 1) * sizeof(int64_t), hipMemcpyDeviceToHost));
+        const int64_t valid = indptr[n];          // all-ones keys (dropped identity entries) sit behind row n-1
+        if (valid) HIP_TRY(hipMemcpy(indices, indices_d.p, valid * sizeof(int32_t), hipMemcpyDeviceToHost));
+        *nnz_out = valid;
+        return 0;
+    }();
+    keys_a.release(); keys_b.release(); colptr_d.release(); indptr_d.release(); indices_d.release(); temp.release();
+    return rc;
 }
 
 int arcte_hip_result_device_rows(arcte_hip_ctx *c, void **rows_dev)

@@ -651,6 +651,56 @@ __global__ void k_to_float(const double *in, float *out, int64_t n)
     if (i < n) out[i] = (float)in[i];
 }
 
+// ---- result assembly: (row, column) pairs -> 64-bit sort keys -> CSR ---------------------------------------
+// local block: seed k's members become (member << 32) | (col_offset + seed id)
+__global__ __launch_bounds__(BLOCK) void k_keys_local(const int32_t *rows, const int64_t *colptr, const int32_t *seeds,
+                                                      int64_t nseeds, uint32_t col_offset, uint64_t *keys)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t k = (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (k >= nseeds) return;
+    const int64_t b = colptr[k], e = colptr[k + 1];
+    const uint64_t col = (uint64_t)col_offset + (uint32_t)seeds[k];
+    for (int64_t i = b + lane; i < e; i += WAVE) keys[i] = ((uint64_t)(uint32_t)rows[i] << 32) | col;
+}
+
+// base block I + pattern(W) (arcte.py:676-679): row i gets its stored columns plus i itself; when the row
+// already stores i (self-loop) the identity entry is dropped here and the host doubles that value instead.
+// Row i writes deg(i) + 1 keys at out_base + indptr[i] + i; a dropped identity entry leaves UINT64_MAX, which
+// sorts to the end and is cut off by the caller.
+__global__ __launch_bounds__(BLOCK) void k_keys_base(const int64_t *indptr, const int32_t *indices, int64_t n, uint64_t *keys)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const int64_t b = indptr[i], e = indptr[i + 1];
+    uint64_t *out = keys + b + i;
+    bool loop = false;
+    for (int64_t k = b + lane; k < e; k += WAVE) {
+        const int32_t c = indices[k];
+        loop |= (c == (int32_t)i);
+        out[k - b] = ((uint64_t)(uint32_t)i << 32) | (uint32_t)c;
+    }
+    const bool any_loop = __ballot(loop) != 0;
+    if (lane == 0) out[e - b] = any_loop ? ~0ull : (((uint64_t)(uint32_t)i << 32) | (uint32_t)i);
+}
+
+// sorted keys -> CSR: indices are the low words, indptr[r] = first position whose row is >= r
+__global__ void k_keys_to_csr(const uint64_t *keys, int64_t nkeys, int64_t n, int32_t *indices, int64_t *indptr)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < nkeys) indices[t] = (int32_t)(uint32_t)keys[t];
+    if (t <= n) {
+        const uint64_t target = (uint64_t)t << 32;
+        int64_t lo = 0, hi = nkeys;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (keys[mid] < target) lo = mid + 1; else hi = mid;
+        }
+        indptr[t] = lo;
+    }
+}
+
 // in_degree[indices[k]] for every stored edge
 __global__ void k_edge_in_degree(const int32_t *indices, const double *in_degree, double *out, int64_t nnz)
 {

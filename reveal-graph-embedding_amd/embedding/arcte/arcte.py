@@ -60,7 +60,8 @@ def _seed_matrix(n, seeds, colptr, rows):
     return sparse.csr_matrix(features)
 
 
-def _worker(variant, iterate_nodes, indices_c, indptr_c, data_c, out_degree, in_degree, rho, epsilon, device):
+def _worker(variant, iterate_nodes, indices_c, indptr_c, data_c, out_degree, in_degree, rho, epsilon, device,
+            with_base_block=False):
     iterate_nodes = np.asarray(iterate_nodes, dtype=np.int64).reshape(-1)
     number_of_nodes = out_degree.size
     laziness_factor = 0.5
@@ -69,6 +70,13 @@ def _worker(variant, iterate_nodes, indices_c, indptr_c, data_c, out_degree, in_
     with _native.Context(indptr_c, indices_c, data_c, out_degree, in_degree, device=device) as ctx:
         ctx.run_seeds(iterate_nodes, rho, epsilon, use_effective_epsilon=True, variant=variant,
                       laziness_factor=laziness_factor)
+        if with_base_block or np.unique(iterate_nodes).size == iterate_nodes.size:
+            # the device sorts the (row, seed) pairs into the CSR the reference builds via COO (arcte.py:379-388)
+            indptr, indices = ctx.fetch_csr(with_base_block)
+            width = 2 * number_of_nodes if with_base_block else number_of_nodes
+            index_dtype = np.int32 if max(width, indices.size) < 2 ** 31 else np.int64
+            return sparse.csr_matrix((np.ones(indices.size, dtype=np.float64), indices,
+                                      indptr.astype(index_dtype)), shape=(number_of_nodes, width))
         colptr, rows = ctx.fetch()
     return _seed_matrix(number_of_nodes, iterate_nodes, colptr, rows)
 
@@ -106,6 +114,10 @@ def seed_nodes(adjacency_matrix):
     iterate_nodes = np.where(edge_count_vector > 1)[0]
     order = np.argsort(-edge_count_vector[iterate_nodes], kind="stable")
     return iterate_nodes[order]
+
+
+_VARIANT_OF = {arcte_worker: _native.ARCTE, arcte_with_pagerank_worker: _native.PAGERANK,
+               arcte_with_lazy_pagerank_worker: _native.LAZY_PAGERANK}
 
 
 def arcte_with_pagerank(adjacency_matrix, rho, epsilon, number_of_threads=None):
@@ -149,6 +161,17 @@ def _arcte_driver(adjacency_matrix, rho, epsilon, number_of_threads, worker):
     rw_transition, out_degree, in_degree = get_natural_random_walk_matrix(adjacency_matrix)
     iterate_nodes = seed_nodes(adjacency_matrix)
 
+    variant = _VARIANT_OF.get(worker)
+    if n_gpus == 1 and variant is not None and rw_transition.nnz + number_of_nodes * 1100 < 2 ** 31:
+        # One GPU: the whole n x 2n pattern [I + pattern(A) | local communities] (arcte.py:676-683) is assembled on
+        # the device; the only values that are not 1 are the diagonal entries of nodes with a self-loop (I + ones).
+        features = _worker(variant, np.sort(iterate_nodes), rw_transition.indices, rw_transition.indptr,
+                           rw_transition.data, out_degree, in_degree, rho, epsilon, 0, with_base_block=True)
+        row_of = np.repeat(np.arange(number_of_nodes), np.diff(rw_transition.indptr))
+        for i in row_of[rw_transition.indices == row_of]:            # stored self-loops: identity + one = 2.0
+            lo, hi = features.indptr[i], features.indptr[i + 1]
+            features.data[lo + np.searchsorted(features.indices[lo:hi], i)] = 2.0
+        return features
     if n_gpus == 1 or iterate_nodes.size < 2:
         # the library orders the work heaviest-first by itself; ascending ids make the result a CSC matrix
         local_features = worker(np.sort(iterate_nodes), rw_transition.indices, rw_transition.indptr, rw_transition.data,
