@@ -330,7 +330,9 @@ int arcte_hip_create(int device, int64_t n, int64_t nnz, const int64_t *indptr, 
         if (slots <= 0) {
             int per_cu = 0;
             HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (k_arcte_seeds<0, 0, double>), BLOCK, 0));
-            per_cu = std::max(1, std::min(per_cu, 8));
+            // 3 workgroups (12 wavefronts) per CU already sit on the random-write wall (slot sweeps: 1M/50M graph
+            // 22.4-22.7 G edges/s from 2048 to 4096 slots); more slots only add footprint
+            per_cu = std::max(1, std::min(per_cu, 3));
             slots = (int64_t)per_cu * c->cus * WAVES_PER_BLOCK;
             // keep the slot scratch within a fixed share of the device
             size_t free_b = 0, total_b = 0;
