@@ -350,11 +350,32 @@ def run_pagerank_variants(name, adjacency, rho, epsilon):
     np.savez_compressed(os.path.join(HERE, name + "_pagerank.npz"), **out)
 
 
+def run_config1_pagerank_hashes():
+    """Full-size spot check of the PageRank flavours on the config-1 R-MAT graph, 8 processes each."""
+    from reveal_graph_embedding.embedding.arcte.arcte import arcte_with_pagerank, arcte_with_lazy_pagerank
+    _, mod = rmat_small()
+    adjacency = mod.rmat_graph(100000, 2000000, seed=0)
+    out = {"rho": np.float64(0.1), "epsilon": np.float64(1e-5)}
+    for tag, driver in (("pr", arcte_with_pagerank), ("lazy", arcte_with_lazy_pagerank)):
+        f = canon(driver(adjacency.copy(), 0.1, 1e-5, 8))
+        h = hashlib.sha256()
+        h.update(f.indptr.astype(np.int64).tobytes())
+        h.update(f.indices.astype(np.int64).tobytes())
+        local = sparse.csc_matrix(f[:, 100000:])
+        out[tag + "_sha256"] = np.frombuffer(h.digest(), dtype=np.uint8)
+        out[tag + "_nnz"] = np.int64(f.nnz)
+        out[tag + "_local_col_counts"] = np.diff(local.indptr).astype(np.int32)
+        print("config-1 R-MAT %s: feature nnz %d sha256 %s" % (tag, f.nnz, h.hexdigest()), flush=True)
+    np.savez_compressed(os.path.join(HERE, "rmat100k_pagerank_summary.npz"), **out)
+
+
 PAGERANK_GRAPHS = ["ba300", "grid25", "corner", "weighted", "selfloop", "directed", "rmat2000"]
 
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["small", "cli"]
+    if "config1_pagerank" in which:
+        run_config1_pagerank_hashes()
     if "pagerank" in which:
         gs = graphs()
         for name in PAGERANK_GRAPHS:

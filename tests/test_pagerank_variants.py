@@ -108,3 +108,37 @@ def test_hip_matches_reference_fixtures_and_oracle(name, tag, variant):
                                                         g["epsilon"], want_stats=True, variant=variant)
     assert np.array_equal(nop, o_nop) and np.array_equal(colptr, o_colptr)
     assert [st["pushes"], st["edges"], st["enqueues"], st["support"]] == list(o_stats)
+
+
+def _config1_check(f, z, tag):
+    import hashlib
+    f.sum_duplicates()
+    f.sort_indices()
+    assert f.nnz == int(z[tag + "_nnz"])
+    local = sparse.csc_matrix(f[:, 100000:])
+    assert np.array_equal(np.diff(local.indptr), z[tag + "_local_col_counts"])
+    h = hashlib.sha256()
+    h.update(f.indptr.astype(np.int64).tobytes())
+    h.update(f.indices.astype(np.int64).tobytes())
+    assert np.array_equal(np.frombuffer(h.digest(), dtype=np.uint8), z[tag + "_sha256"])
+
+
+@pytest.mark.parametrize("tag,variant", FLAVOURS)
+def test_oracle_config1_full_size_hash(tag, variant):
+    """All 63 070 seeds of the config-1 R-MAT graph against the reference's own 8-process run."""
+    from reveal_graph_embedding_amd.synthetic import rmat_graph
+    z = np.load(os.path.join(GOLDEN, "rmat100k_pagerank_summary.npz"))
+    adjacency = rmat_graph(100000, 2000000, seed=0)
+    f = oracle.arcte(adjacency, float(z["rho"]), float(z["epsilon"]), oracle.lib().oracle_max_threads(), variant=variant)
+    _config1_check(f, z, tag)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag,variant", FLAVOURS)
+def test_hip_config1_full_size_hash(tag, variant):
+    from reveal_graph_embedding_amd.embedding.arcte import arcte as A
+    from reveal_graph_embedding_amd.synthetic import rmat_graph
+    z = np.load(os.path.join(GOLDEN, "rmat100k_pagerank_summary.npz"))
+    adjacency = rmat_graph(100000, 2000000, seed=0)
+    driver = A.arcte_with_pagerank if tag == "pr" else A.arcte_with_lazy_pagerank
+    _config1_check(driver(adjacency, float(z["rho"]), float(z["epsilon"]), 1), z, tag)
