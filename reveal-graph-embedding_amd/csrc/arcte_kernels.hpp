@@ -321,7 +321,11 @@ __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
         if (lane == 0) w = atomicAdd(P.work_counter, 1ULL);
         return bcast_u64(w);
     };
-    for (unsigned long long wk = next_work(); wk < (unsigned long long)P.nwork; wk = next_work()) {
+    // (the extra bound is insurance only: a wave can draw at most nwork items, so a loop that ever ran past that
+    //  would be a compiler-induced divergence like the one described above, and must still terminate)
+    unsigned long long drawn = 0;
+    for (unsigned long long wk = next_work(); wk < (unsigned long long)P.nwork && drawn <= (unsigned long long)P.nwork;
+         wk = next_work(), drawn++) {
         const int32_t pos = P.work_pos ? P.work_pos[wk] : (int32_t)wk;
         const int32_t seed = P.seeds[pos];
         const T eps = (T)P.eps[pos];
