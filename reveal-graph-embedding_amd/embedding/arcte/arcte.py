@@ -2,6 +2,7 @@
 (reference lines 14-50, 279-388, 591-688).  The propagation, the effective-epsilon rule and the
 community extraction all run in HIP kernels behind reveal_graph_embedding_amd._native."""
 import itertools
+import os
 import threading
 
 import numpy as np
@@ -155,8 +156,13 @@ def _arcte_driver(adjacency_matrix, rho, epsilon, number_of_threads, worker):
     n_gpus = _native.device_count()
     if n_gpus < 1:
         raise _native.ArcteHipError(-2, "no HIP device visible (there is no CPU fallback)")
+    devices = list(range(n_gpus))
+    if os.environ.get("ARCTE_HIP_DEVICES"):
+        # explicit placement, one worker per listed device id (ids may repeat: several workers on one GPU)
+        devices = [int(x) for x in os.environ["ARCTE_HIP_DEVICES"].split(",")]
     if number_of_threads is not None:
-        n_gpus = max(1, min(n_gpus, int(number_of_threads)))
+        devices = devices[:max(1, int(number_of_threads))]
+    n_gpus = len(devices)
 
     rw_transition, out_degree, in_degree = get_natural_random_walk_matrix(adjacency_matrix)
     iterate_nodes = seed_nodes(adjacency_matrix)
@@ -166,7 +172,7 @@ def _arcte_driver(adjacency_matrix, rho, epsilon, number_of_threads, worker):
         # One GPU: the whole n x 2n pattern [I + pattern(A) | local communities] (arcte.py:676-683) is assembled on
         # the device; the only values that are not 1 are the diagonal entries of nodes with a self-loop (I + ones).
         features = _worker(variant, np.sort(iterate_nodes), rw_transition.indices, rw_transition.indptr,
-                           rw_transition.data, out_degree, in_degree, rho, epsilon, 0, with_base_block=True)
+                           rw_transition.data, out_degree, in_degree, rho, epsilon, devices[0], with_base_block=True)
         row_of = np.repeat(np.arange(number_of_nodes), np.diff(rw_transition.indptr))
         for i in row_of[rw_transition.indices == row_of]:            # stored self-loops: identity + one = 2.0
             lo, hi = features.indptr[i], features.indptr[i + 1]
@@ -185,7 +191,7 @@ def _arcte_driver(adjacency_matrix, rho, epsilon, number_of_threads, worker):
             try:
                 if chunks[k] is not None:
                     results[k] = worker(chunks[k], rw_transition.indices, rw_transition.indptr,
-                                        rw_transition.data, out_degree, in_degree, rho, epsilon, device=k)
+                                        rw_transition.data, out_degree, in_degree, rho, epsilon, device=devices[k])
             except BaseException as e:  # surfaced below; the reference drops worker errors silently
                 errors.append(e)
 

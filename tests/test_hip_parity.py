@@ -313,3 +313,16 @@ def test_degenerate_graphs_and_seed_lists():
     # duplicate seeds write the same column twice: COO -> CSR sums them, exactly like the reference's coo_matrix
     want = oracle.worker_matrix(g["w"], g["out_degree"], g["in_degree"], seeds, g["rho"], g["epsilon"])
     assert_same_sparse(got, want)
+
+
+def test_in_process_multi_worker_path(monkeypatch):
+    """arcte() with several workers in one process (one host thread + one context per worker, seeds dealt
+    round-robin, results summed: arcte.py:650-673).  Both workers are placed on GPU 0 here."""
+    monkeypatch.setenv("ARCTE_HIP_DEVICES", "0,0,0")
+    for name in ("rmat2000", "selfloop", "corner"):
+        g = load_golden(name)
+        got = arcte(g["adjacency"], g["rho"], g["epsilon"], 3)
+        assert_same_sparse(got, g["feat3"])
+    monkeypatch.setenv("ARCTE_HIP_DEVICES", "0")
+    g = load_golden("ba300")
+    assert_same_sparse(arcte(g["adjacency"], g["rho"], g["epsilon"], None), g["feat1"])
