@@ -210,7 +210,8 @@ int launch_seeds_v(arcte_hip_ctx *c, const PushParams &P, int64_t nwork)
     // MODE 1 works on the dense vectors the host placed in slot 0: exactly one wavefront may run
     const int threads = (MODE == 1) ? WAVE : BLOCK;
     if (MODE == 1) blocks = 1;
-    hipLaunchKernelGGL((k_arcte_seeds<MODE, VAR, T>), dim3(blocks), dim3(threads), 0, c->stream, P);
+    // 2 x 64 edges per iteration; 4 x 64 measured the same at every slot count (124 instead of 103 VGPRs)
+    hipLaunchKernelGGL((k_arcte_seeds<MODE, VAR, T, 2>), dim3(blocks), dim3(threads), 0, c->stream, P);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -329,10 +330,11 @@ int arcte_hip_create(int device, int64_t n, int64_t nnz, const int64_t *indptr, 
         int64_t slots = n_slots;
         if (slots <= 0) {
             int per_cu = 0;
-            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (k_arcte_seeds<0, 0, double>), BLOCK, 0));
-            // 3 workgroups (12 wavefronts) per CU already sit on the random-write wall (slot sweeps: 1M/50M graph
-            // 22.4-22.7 G edges/s from 2048 to 4096 slots); more slots only add footprint
-            per_cu = std::max(1, std::min(per_cu, 3));
+            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (k_arcte_seeds<0, 0, double, 2>), BLOCK, 0));
+            // 2 workgroups (8 wavefronts) per CU already sit on the random-write wall (slot sweeps on the 1M/50M
+            // graph: 22.4-22.7 G edges/s from 2048 to 4096 slots, ~600 k seeds/s already at 1024); more slots only
+            // add footprint
+            per_cu = std::max(1, std::min(per_cu, 2));
             slots = (int64_t)per_cu * c->cus * WAVES_PER_BLOCK;
             // keep the slot scratch within a fixed share of the device
             size_t free_b = 0, total_b = 0;

@@ -296,7 +296,7 @@ struct PushParams {
 // VAR 0: cumulative PageRank difference (push.py:41-64, similarity.py:149-222) -- ARCTE proper.
 // VAR 1: PageRank limit push (push.py:4-17, similarity.py:11-63).
 // VAR 2: lazy PageRank push (push.py:20-38, similarity.py:66-146) with its self re-push loops.
-template <int MODE, int VAR, typename T>
+template <int MODE, int VAR, typename T, int TILES>
 __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
 {
     const int lane = threadIdx.x & 63;
@@ -380,25 +380,34 @@ __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
                 nsup += g1;
                 nfirst += g1;
             }
-            for (int64_t base = rb; base < re; base += 2 * WAVE) {
-                const int64_t k0 = base + lane, k1 = k0 + WAVE;
-                const bool a0 = k0 < re, a1 = k1 < re;
-                int32_t v0 = 0, v1 = 0;
-                T w0 = T(0), w1 = T(0), d0 = T(1), d1 = T(1);
-                if (a0) { v0 = g.indices[k0]; w0 = gv.data[k0]; d0 = gv.edge_in_degree[k0]; }
-                if (a1) { v1 = g.indices[k1]; w1 = gv.data[k1]; d1 = gv.edge_in_degree[k1]; }
-                LoT<T> l0 = {T(0), T(0)}, l1 = {T(0), T(0)};
-                HiT<T> h0 = {T(1), 0u}, h1 = {T(1), 0u};
-                if (a0) { l0 = load_lo(st + v0); h0 = load_hi(st + v0); }
-                if (a1) { l1 = load_lo(st + v1); h1 = load_hi(st + v1); }
+            for (int64_t base = rb; base < re; base += TILES * WAVE) {
+                // TILES x 64 edges per iteration: every load of the iteration is issued before the first use
+                bool a_[TILES];
+                int32_t v_[TILES];
+                T w_[TILES], d_[TILES];
+                LoT<T> l_[TILES];
+                HiT<T> h_[TILES];
 #pragma unroll
-                for (int t = 0; t < 2; t++) {
-                    const bool act = t ? a1 : a0;
-                    const int32_t v = t ? v1 : v0;
-                    const T w = t ? w1 : w0;
-                    const T dv = t ? d1 : d0;
-                    const LoT<T> lo = t ? l1 : l0;
-                    const bool live = (t ? h1.epoch : h0.epoch) == epoch;
+                for (int t = 0; t < TILES; t++) {
+                    const int64_t k = base + t * WAVE + lane;
+                    a_[t] = k < re;
+                    v_[t] = 0; w_[t] = T(0); d_[t] = T(1);
+                    if (a_[t]) { v_[t] = g.indices[k]; w_[t] = gv.data[k]; d_[t] = gv.edge_in_degree[k]; }
+                }
+#pragma unroll
+                for (int t = 0; t < TILES; t++) {
+                    l_[t] = {T(0), T(0)};
+                    h_[t] = {T(1), 0u};
+                    if (a_[t]) { l_[t] = load_lo(st + v_[t]); h_[t] = load_hi(st + v_[t]); }
+                }
+#pragma unroll
+                for (int t = 0; t < TILES; t++) {
+                    const bool act = a_[t];
+                    const int32_t v = v_[t];
+                    const T w = w_[t];
+                    const T dv = d_[t];
+                    const LoT<T> lo = l_[t];
+                    const bool live = h_[t].epoch == epoch;
                     const T p = c * w;                                  // push.py:62 / :17 / :38
                     const T r_old = live ? ((v != u) ? lo.r : r_self) : T(0);   // a self-loop sees r[u] as just set
                     const T s_old = live ? lo.s : T(0);
