@@ -728,7 +728,12 @@ int arcte_hip_fetch_result_csr(arcte_hip_ctx *c, int with_base_block, int64_t *i
     const int64_t n = c->n, ns = c->run_nseeds;
     const int64_t nbase = with_base_block ? c->nnz + n : 0;
     const int64_t nkeys = nbase + c->final_rows;
-    if (nkeys >= ((int64_t)1 << 31)) return fail(ARCTE_HIP_ECAPACITY, "more than 2^31 entries: assemble on the host instead");
+    int64_t key_limit = (int64_t)1 << 31;
+    if (const char *env = getenv("ARCTE_HIP_MAX_SORT_KEYS")) {      // test hook: force the host-assembly fallback
+        long long v = atoll(env);
+        if (v > 0) key_limit = std::min<int64_t>(key_limit, v);
+    }
+    if (nkeys >= key_limit) return fail(ARCTE_HIP_ECAPACITY, "too many entries for the device key sort: assemble on the host instead");
     if (nkeys && !indices) return fail(ARCTE_HIP_EINVAL, "indices is NULL");
     DevBuf<uint64_t> keys_a, keys_b;
     DevBuf<int64_t> colptr_d, indptr_d;

@@ -61,6 +61,19 @@ def _seed_matrix(n, seeds, colptr, rows):
     return sparse.csr_matrix(features)
 
 
+def _finish_base_values(features, rw_transition):
+    """The device-assembled pattern stores ONE diagonal entry for a node with a self-loop; the reference's
+    identity + ones (arcte.py:676-679) makes that value 2.0.  (The host-assembled fallback already has it.)"""
+    if rw_transition is None:
+        return features
+    n = rw_transition.shape[0]
+    row_of = np.repeat(np.arange(n), np.diff(rw_transition.indptr))
+    for i in row_of[rw_transition.indices == row_of]:
+        lo, hi = features.indptr[i], features.indptr[i + 1]
+        features.data[lo + np.searchsorted(features.indices[lo:hi], i)] = 2.0
+    return features
+
+
 def _worker(variant, iterate_nodes, indices_c, indptr_c, data_c, out_degree, in_degree, rho, epsilon, device,
             with_base_block=False):
     iterate_nodes = np.asarray(iterate_nodes, dtype=np.int64).reshape(-1)
@@ -73,13 +86,24 @@ def _worker(variant, iterate_nodes, indices_c, indptr_c, data_c, out_degree, in_
                       laziness_factor=laziness_factor)
         if with_base_block or np.unique(iterate_nodes).size == iterate_nodes.size:
             # the device sorts the (row, seed) pairs into the CSR the reference builds via COO (arcte.py:379-388)
-            indptr, indices = ctx.fetch_csr(with_base_block)
-            width = 2 * number_of_nodes if with_base_block else number_of_nodes
-            index_dtype = np.int32 if max(width, indices.size) < 2 ** 31 else np.int64
-            return sparse.csr_matrix((np.ones(indices.size, dtype=np.float64), indices,
-                                      indptr.astype(index_dtype)), shape=(number_of_nodes, width))
+            try:
+                indptr, indices = ctx.fetch_csr(with_base_block)
+            except _native.ArcteHipError as e:
+                if e.code != -3:                      # ARCTE_HIP_ECAPACITY: too many entries for the 32-bit key sort
+                    raise
+            else:
+                width = 2 * number_of_nodes if with_base_block else number_of_nodes
+                index_dtype = np.int32 if max(width, indices.size) < 2 ** 31 else np.int64
+                return sparse.csr_matrix((np.ones(indices.size, dtype=np.float64), indices,
+                                          indptr.astype(index_dtype)), shape=(number_of_nodes, width))
         colptr, rows = ctx.fetch()
-    return _seed_matrix(number_of_nodes, iterate_nodes, colptr, rows)
+    local = _seed_matrix(number_of_nodes, iterate_nodes, colptr, rows)
+    if not with_base_block:
+        return local
+    pattern = sparse.csr_matrix((np.ones(len(data_c), dtype=np.float64), indices_c, indptr_c),
+                                shape=(number_of_nodes, number_of_nodes))
+    base = sparse.csr_matrix(sparse.eye(number_of_nodes, number_of_nodes, dtype=np.float64)) + pattern
+    return _finish_base_values(sparse.hstack([base, local]).tocsr(), None)
 
 
 def arcte_worker(iterate_nodes, indices_c, indptr_c, data_c, out_degree, in_degree, rho, epsilon, device=0):
@@ -173,11 +197,7 @@ def _arcte_driver(adjacency_matrix, rho, epsilon, number_of_threads, worker):
         # the device; the only values that are not 1 are the diagonal entries of nodes with a self-loop (I + ones).
         features = _worker(variant, np.sort(iterate_nodes), rw_transition.indices, rw_transition.indptr,
                            rw_transition.data, out_degree, in_degree, rho, epsilon, devices[0], with_base_block=True)
-        row_of = np.repeat(np.arange(number_of_nodes), np.diff(rw_transition.indptr))
-        for i in row_of[rw_transition.indices == row_of]:            # stored self-loops: identity + one = 2.0
-            lo, hi = features.indptr[i], features.indptr[i + 1]
-            features.data[lo + np.searchsorted(features.indices[lo:hi], i)] = 2.0
-        return features
+        return _finish_base_values(features, rw_transition)
     if n_gpus == 1 or iterate_nodes.size < 2:
         # the library orders the work heaviest-first by itself; ascending ids make the result a CSC matrix
         local_features = worker(np.sort(iterate_nodes), rw_transition.indices, rw_transition.indptr, rw_transition.data,

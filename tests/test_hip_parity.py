@@ -326,3 +326,13 @@ def test_in_process_multi_worker_path(monkeypatch):
     monkeypatch.setenv("ARCTE_HIP_DEVICES", "0")
     g = load_golden("ba300")
     assert_same_sparse(arcte(g["adjacency"], g["rho"], g["epsilon"], None), g["feat1"])
+
+
+def test_host_assembly_fallback_when_the_device_sort_is_too_small(monkeypatch):
+    monkeypatch.setenv("ARCTE_HIP_MAX_SORT_KEYS", "1000")
+    for name in ("rmat2000", "selfloop"):
+        g = load_golden(name)
+        assert_same_sparse(arcte(g["adjacency"], g["rho"], g["epsilon"], 1), g["feat1"])
+        got = arcte_worker(g["seeds"], g["w"].indices, g["w"].indptr, g["w"].data, g["out_degree"], g["in_degree"],
+                           g["rho"], g["epsilon"])
+        assert_same_sparse(got, g["worker"])
