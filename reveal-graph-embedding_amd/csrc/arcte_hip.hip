@@ -61,13 +61,28 @@ struct DevBuf {
     {
         release();
         count = c;
-        return hipMalloc((void **)&p, std::max<size_t>(c, 1) * sizeof(T));
+        hipError_t e = hipMalloc((void **)&p, std::max<size_t>(c, 1) * sizeof(T));
+        if (e == hipSuccess) capacity = std::max<size_t>(c, 1);
+        return e;
+    }
+    // grow-only variant for per-run buffers: a repeated run of the same size allocates nothing
+    size_t capacity = 0;
+    hipError_t reserve(size_t c)
+    {
+        if (p && c <= capacity) {
+            count = c;
+            return hipSuccess;
+        }
+        hipError_t e = alloc(c);
+        if (e == hipSuccess) capacity = std::max<size_t>(c, 1);
+        return e;
     }
     void release()
     {
         if (p) (void)hipFree(p);
         p = nullptr;
         count = 0;
+        capacity = 0;
     }
     size_t bytes() const { return count * sizeof(T); }
 };
@@ -135,6 +150,9 @@ struct arcte_hip_ctx {
     DevBuf<int64_t> out_off, dst_off;
     DevBuf<unsigned long long> counters;   // [0] work counter [1] raw cursor [2..6] stats
     DevBuf<int32_t> raw, rows_final;
+    DevBuf<uint64_t> sort_keys;
+    DevBuf<int32_t> sort_iota;
+    DevBuf<char> sort_temp;
     int64_t raw_for_seeds = 0;
     int64_t final_rows = 0;
     std::vector<int64_t> colptr;
@@ -369,7 +387,7 @@ int arcte_hip_destroy(arcte_hip_ctx *c)
     c->state.release(); c->slot_epoch.release(); c->edge_in_degree.release(); c->data_f.release(); c->in_degree_f.release(); c->edge_in_degree_f.release(); c->queue.release(); c->sup.release();
     c->seeds_d.release(); c->work_pos.release(); c->out_cnt.release(); c->status.release(); c->nop_d.release();
     c->eps_d.release(); c->out_off.release(); c->dst_off.release(); c->counters.release();
-    c->raw.release(); c->rows_final.release();
+    c->raw.release(); c->rows_final.release(); c->sort_keys.release(); c->sort_iota.release(); c->sort_temp.release();
     for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -383,8 +401,8 @@ static int upload_seeds(arcte_hip_ctx *c, const int64_t *seeds, int64_t nseeds)
         if (seeds[k] < 0 || seeds[k] >= c->n) return fail(ARCTE_HIP_EINVAL, "seed id out of range");
         s32[k] = (int32_t)seeds[k];
     }
-    HIP_TRY(c->seeds_d.alloc(nseeds));
-    HIP_TRY(c->eps_d.alloc(nseeds));
+    HIP_TRY(c->seeds_d.reserve(nseeds));
+    HIP_TRY(c->eps_d.reserve(nseeds));
     if (nseeds) HIP_TRY(hipMemcpy(c->seeds_d.p, s32.data(), nseeds * sizeof(int32_t), hipMemcpyHostToDevice));
     return 0;
 }
@@ -439,12 +457,12 @@ static int run_seeds_impl(arcte_hip_ctx *c, const int64_t *seeds, int64_t nseeds
         HIP_TRY(hipMemsetAsync(c->slot_epoch.p, 0, c->slot_epoch.bytes(), c->stream));
         c->seeds_since_clear = (uint64_t)nseeds;
     }
-    HIP_TRY(c->out_cnt.alloc(nseeds));
-    HIP_TRY(c->status.alloc(nseeds));
-    HIP_TRY(c->nop_d.alloc(nseeds));
-    HIP_TRY(c->out_off.alloc(nseeds));
-    HIP_TRY(c->dst_off.alloc(nseeds));
-    HIP_TRY(c->work_pos.alloc(nseeds));
+    HIP_TRY(c->out_cnt.reserve(nseeds));
+    HIP_TRY(c->status.reserve(nseeds));
+    HIP_TRY(c->nop_d.reserve(nseeds));
+    HIP_TRY(c->out_off.reserve(nseeds));
+    HIP_TRY(c->dst_off.reserve(nseeds));
+    HIP_TRY(c->work_pos.reserve(nseeds));
     c->colptr.assign((size_t)nseeds + 1, 0);
     if (nseeds == 0) {
         c->run_nseeds = 0;
@@ -497,24 +515,19 @@ static int run_seeds_impl(arcte_hip_ctx *c, const int64_t *seeds, int64_t nseeds
     for (int64_t k = 0; k < nseeds; k++) work[k] = (int32_t)k;
     bool sorted_on_device = false;
     if (use_effective_epsilon) {
-        DevBuf<uint64_t> keys_out;
-        DevBuf<int32_t> iota;
-        DevBuf<char> temp;
         int rs = [&]() -> int {
-            HIP_TRY(keys_out.alloc(nseeds));
-            HIP_TRY(iota.alloc(nseeds));
-            HIP_TRY(hipMemcpyAsync(iota.p, work.data(), nseeds * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(c->sort_keys.reserve(nseeds));
+            HIP_TRY(c->sort_iota.reserve(nseeds));
+            HIP_TRY(hipMemcpyAsync(c->sort_iota.p, work.data(), nseeds * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
             size_t temp_bytes = 0;
             const uint64_t *keys_in = reinterpret_cast<const uint64_t *>(c->eps_d.p);   // positive doubles order like their bits
-            HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, keys_in, keys_out.p, iota.p, c->work_pos.p,
+            HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, keys_in, c->sort_keys.p, c->sort_iota.p, c->work_pos.p,
                                                        (int)nseeds, 0, 64, c->stream));
-            HIP_TRY(temp.alloc(temp_bytes));
-            HIP_TRY(hipcub::DeviceRadixSort::SortPairs(temp.p, temp_bytes, keys_in, keys_out.p, iota.p, c->work_pos.p,
-                                                       (int)nseeds, 0, 64, c->stream));
-            HIP_TRY(hipStreamSynchronize(c->stream));
+            HIP_TRY(c->sort_temp.reserve(temp_bytes));
+            HIP_TRY(hipcub::DeviceRadixSort::SortPairs(c->sort_temp.p, temp_bytes, keys_in, c->sort_keys.p, c->sort_iota.p,
+                                                       c->work_pos.p, (int)nseeds, 0, 64, c->stream));
             return 0;
         }();
-        keys_out.release(); iota.release(); temp.release();
         if (rs) return rs;
         sorted_on_device = true;
     } else {
