@@ -44,7 +44,7 @@ def _worker(rank, world, port, name, out_path):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,name", [(2, "ba300"), (2, "corner"), (3, "rmat2000")])
+@pytest.mark.parametrize("world,name", [(2, "ba300"), (2, "corner"), (3, "rmat2000"), (4, "grid25"), (8, "ba300")])
 def test_sharded_arcte_equals_reference_fixture(tmp_path, world, name):
     import scipy.sparse as sparse
     out = str(tmp_path / "f.npz")
