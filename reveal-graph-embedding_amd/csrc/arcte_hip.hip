@@ -151,7 +151,7 @@ struct arcte_hip_ctx {
     DevBuf<unsigned long long> counters;   // [0] work counter [1] raw cursor [2..6] stats
     DevBuf<int32_t> raw, rows_final;
     DevBuf<uint64_t> sort_keys;
-    DevBuf<int32_t> sort_iota;
+    DevBuf<int32_t> sort_iota, eps_big_pos;
     DevBuf<char> sort_temp;
     int64_t raw_for_seeds = 0;
     int64_t final_rows = 0;
@@ -387,7 +387,7 @@ int arcte_hip_destroy(arcte_hip_ctx *c)
     c->state.release(); c->slot_epoch.release(); c->edge_in_degree.release(); c->data_f.release(); c->in_degree_f.release(); c->edge_in_degree_f.release(); c->queue.release(); c->sup.release();
     c->seeds_d.release(); c->work_pos.release(); c->out_cnt.release(); c->status.release(); c->nop_d.release();
     c->eps_d.release(); c->out_off.release(); c->dst_off.release(); c->counters.release();
-    c->raw.release(); c->rows_final.release(); c->sort_keys.release(); c->sort_iota.release(); c->sort_temp.release();
+    c->raw.release(); c->rows_final.release(); c->sort_keys.release(); c->sort_iota.release(); c->sort_temp.release(); c->eps_big_pos.release();
     for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -407,13 +407,25 @@ static int upload_seeds(arcte_hip_ctx *c, const int64_t *seeds, int64_t nseeds)
     return 0;
 }
 
-static int launch_eps(arcte_hip_ctx *c, int64_t nseeds, double epsilon)
+static int launch_eps(arcte_hip_ctx *c, const int64_t *seeds, int64_t nseeds, double epsilon)
 {
     if (nseeds == 0) return 0;
     int blocks = (int)((nseeds + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
     hipLaunchKernelGGL(k_epsilon_effective, dim3(blocks), dim3(BLOCK), 0, c->stream, c->graph(), c->seeds_d.p, nseeds,
                        epsilon, c->eps_d.p);
     HIP_TRY(hipGetLastError());
+    // rows too long for one wavefront get a workgroup each
+    std::vector<int32_t> big;
+    for (int64_t k = 0; k < nseeds; k++)
+        if (c->row_len[(size_t)seeds[k]] >= EPS_BIG_ROW) big.push_back((int32_t)k);
+    if (!big.empty()) {
+        HIP_TRY(c->eps_big_pos.reserve(big.size()));
+        HIP_TRY(hipMemcpyAsync(c->eps_big_pos.p, big.data(), big.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(k_epsilon_effective_big, dim3((unsigned)big.size()), dim3(EPS_BIG_WAVES * WAVE), 0, c->stream,
+                           c->graph(), c->seeds_d.p, c->eps_big_pos.p, (int64_t)big.size(), epsilon, c->eps_d.p);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(c->stream));     // `big` is a host temporary
+    }
     return 0;
 }
 
@@ -424,7 +436,7 @@ int arcte_hip_epsilon_effective(arcte_hip_ctx *c, const int64_t *seeds, int64_t 
     c->run_nseeds = -1;
     int r = upload_seeds(c, seeds, nseeds);
     if (r) return r;
-    r = launch_eps(c, nseeds, epsilon);
+    r = launch_eps(c, seeds, nseeds, epsilon);
     if (r) return r;
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (nseeds) HIP_TRY(hipMemcpy(eps_out, c->eps_d.p, nseeds * sizeof(double), hipMemcpyDeviceToHost));
@@ -472,7 +484,7 @@ static int run_seeds_impl(arcte_hip_ctx *c, const int64_t *seeds, int64_t nseeds
     // a4
     HIP_TRY(hipEventRecord(c->ev[0], c->stream));
     if (use_effective_epsilon) {
-        r = launch_eps(c, nseeds, epsilon);
+        r = launch_eps(c, seeds, nseeds, epsilon);
         if (r) return r;
     } else {
         std::vector<double> e((size_t)nseeds, epsilon);

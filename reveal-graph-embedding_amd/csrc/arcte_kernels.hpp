@@ -121,25 +121,13 @@ __device__ double pw_leaf(const GraphDev &g, int64_t lo, int64_t n, double *leaf
     return res;
 }
 
-__global__ __launch_bounds__(BLOCK) void k_epsilon_effective(GraphDev g, const int32_t *seeds, int64_t nseeds,
-                                                             double epsilon, double *eps_out)
+// numpy's pairwise float64 sum (oracle: np_pairwise) of a[i] = out_degree[indices[lo + i]], i < n, by one
+// wavefront: the recursion is evaluated with an explicit frame stack in LDS; min/max of a are folded in.
+__device__ double pw_sum_wave(const GraphDev &g, int64_t lo, int64_t n, EpsShared &S, int lane, double &amin, double &amax)
 {
-    __shared__ EpsShared sh[WAVES_PER_BLOCK];
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    EpsShared &S = sh[wave];
-    const int64_t k = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wave;
-    if (k >= nseeds) return;
-    const int32_t seed = seeds[k];
-    const int64_t b = g.indptr[seed];
-    const int64_t m = g.indptr[seed + 1] - b;
-    const double ds = g.out_degree[seed];
-    double amin = INFINITY, amax = -INFINITY;
-
-    // pairwise recursion of numpy's float64 add.reduce, evaluated with an explicit frame stack
     int sp = 0;
     double ret = 0.0;
-    if (lane == 0) { S.frames[0].lo = b; S.frames[0].n = m; S.frames[0].stage = 0; }
+    if (lane == 0) { S.frames[0].lo = lo; S.frames[0].n = n; S.frames[0].stage = 0; }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     while (sp >= 0) {
         const int64_t flo = S.frames[sp].lo;
@@ -171,19 +159,84 @@ __global__ __launch_bounds__(BLOCK) void k_epsilon_effective(GraphDev g, const i
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     }
+    return ret;
+}
+
+// arcte.py:32-48 from the reduced neighbour degrees
+__device__ __forceinline__ double epsilon_from_stats(double epsilon, double ds, double sum, int64_t m, double amin, double amax)
+{
+    double mean = sum / (double)m;                                            // arcte.py:32
+    double e = (epsilon * log(1 + ds)) / log(1 + mean);                       // :35
+    // :39-40  max/min over i of 1/(ds*a_i): correctly rounded * and / are monotone, so the
+    // extrema sit at the extrema of a_i
+    double emax = 1 / (ds * amin);
+    double emin = 1 / (ds * amax);
+    if (m == 0) { emax = -INFINITY; emin = INFINITY; }
+    if (e > emax) e = emax;                                                   // :45-48
+    else if (e < emin) e = (emin + e) / 2;
+    return e;
+}
+
+// Rows of at least EPS_BIG_ROW neighbours go to k_epsilon_effective_big: one wavefront would walk them leaf by
+// leaf (the 127 441-neighbour hub of the 1M/50M graph alone took 3 ms, the whole kernel's duration).
+constexpr int64_t EPS_BIG_ROW = 4096;
+constexpr int EPS_BIG_WAVES = 16;      // = 2^4 subtrees of numpy's recursion
+
+__global__ __launch_bounds__(BLOCK) void k_epsilon_effective(GraphDev g, const int32_t *seeds, int64_t nseeds,
+                                                             double epsilon, double *eps_out)
+{
+    __shared__ EpsShared sh[WAVES_PER_BLOCK];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int64_t k = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wave;
+    if (k >= nseeds) return;
+    const int32_t seed = seeds[k];
+    const int64_t b = g.indptr[seed];
+    const int64_t m = g.indptr[seed + 1] - b;
+    if (m >= EPS_BIG_ROW) return;                    // handled by k_epsilon_effective_big
+    double amin = INFINITY, amax = -INFINITY;
+    const double sum = pw_sum_wave(g, b, m, sh[wave], lane, amin, amax);
     amin = wave_min(amin);
     amax = wave_max(amax);
-    if (lane == 0) {
-        double mean = ret / (double)m;                                            // arcte.py:32
-        double e = (epsilon * log(1 + ds)) / log(1 + mean);                       // :35
-        // :39-40  max/min over i of 1/(ds*a_i): correctly rounded * and / are monotone, so the
-        // extrema sit at the extrema of a_i
-        double emax = 1 / (ds * amin);
-        double emin = 1 / (ds * amax);
-        if (m == 0) { emax = -INFINITY; emin = INFINITY; }
-        if (e > emax) e = emax;                                                   // :45-48
-        else if (e < emin) e = (emin + e) / 2;
-        eps_out[k] = e;
+    if (lane == 0) eps_out[k] = epsilon_from_stats(epsilon, g.out_degree[seed], sum, m, amin, amax);
+}
+
+// One workgroup of 16 wavefronts per big row: wavefront w evaluates subtree w of the fourth level of numpy's
+// pairwise recursion (the split points are the recursion's own), the partial sums are combined in the
+// recursion's order, so the result is bit-identical to the one-wavefront evaluation.
+__global__ __launch_bounds__(EPS_BIG_WAVES * WAVE) void k_epsilon_effective_big(GraphDev g, const int32_t *seeds,
+                                                                              const int32_t *big_pos, int64_t nbig,
+                                                                              double epsilon, double *eps_out)
+{
+    __shared__ EpsShared sh[EPS_BIG_WAVES];
+    __shared__ double part[EPS_BIG_WAVES], pmin[EPS_BIG_WAVES], pmax[EPS_BIG_WAVES];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int64_t k = big_pos[blockIdx.x];
+    const int32_t seed = seeds[k];
+    const int64_t b = g.indptr[seed];
+    const int64_t m = g.indptr[seed + 1] - b;
+    int64_t lo = b, n = m;
+    for (int level = 3; level >= 0; level--) {       // m >= 4096 keeps every node of the first four levels > 128
+        int64_t n2 = n / 2;
+        n2 -= n2 % 8;
+        if ((wave >> level) & 1) { lo += n2; n -= n2; }
+        else n = n2;
+    }
+    double amin = INFINITY, amax = -INFINITY;
+    const double sum = pw_sum_wave(g, lo, n, sh[wave], lane, amin, amax);
+    amin = wave_min(amin);
+    amax = wave_max(amax);
+    if (lane == 0) { part[wave] = sum; pmin[wave] = amin; pmax[wave] = amax; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t[EPS_BIG_WAVES];
+        for (int i = 0; i < EPS_BIG_WAVES; i++) t[i] = part[i];
+        for (int width = EPS_BIG_WAVES; width > 1; width >>= 1)
+            for (int i = 0; i < width / 2; i++) t[i] = t[2 * i] + t[2 * i + 1];      // left + right at every level
+        double mn = pmin[0], mx = pmax[0];
+        for (int i = 1; i < EPS_BIG_WAVES; i++) { mn = pmin[i] < mn ? pmin[i] : mn; mx = pmax[i] > mx ? pmax[i] : mx; }
+        eps_out[k] = epsilon_from_stats(epsilon, g.out_degree[seed], t[0], m, mn, mx);
     }
 }
 

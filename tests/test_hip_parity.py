@@ -336,3 +336,29 @@ def test_host_assembly_fallback_when_the_device_sort_is_too_small(monkeypatch):
         got = arcte_worker(g["seeds"], g["w"].indices, g["w"].indptr, g["w"].data, g["out_degree"], g["in_degree"],
                            g["rho"], g["epsilon"])
         assert_same_sparse(got, g["worker"])
+
+
+def test_epsilon_effective_on_big_weighted_rows():
+    """Rows beyond 4096 neighbours take the workgroup-per-row kernel (16 subtrees of numpy's pairwise
+    recursion); with random weights the summation ORDER shows in the last bits, so bit-identity with the
+    oracle on (nearly) every seed proves the order."""
+    a = rmat_graph(100000, 2000000, seed=0)
+    rng = np.random.default_rng(5)
+    u = sparse.triu(a, k=1).tocoo()
+    wts = rng.uniform(0.05, 7.0, size=u.nnz)
+    wa = sparse.coo_matrix((wts, (u.row, u.col)), shape=a.shape)
+    wa = sparse.csr_matrix(wa + wa.T)
+    w, od, idg = get_natural_random_walk_matrix(wa)
+    deg = np.diff(w.indptr)
+    big = np.flatnonzero(deg >= 4096)
+    assert big.size >= 5
+    seeds = np.concatenate([big, rng.choice(np.flatnonzero((deg > 1) & (deg < 4096)), size=300, replace=False)])
+    with _native.Context(w.indptr, w.indices, w.data, od, idg, n_slots=64) as ctx:
+        got = ctx.epsilon_effective(seeds, 1e-5)
+    want = np.array([oracle.calculate_epsilon_effective(0.1, 1e-5, od[s], od[w.indices[w.indptr[s]:w.indptr[s + 1]]])
+                     for s in seeds])
+    np.testing.assert_allclose(got, want, rtol=EPS_RTOL, atol=0)
+    same_big = int((got[:big.size] == want[:big.size]).sum())
+    print("big rows: %d, bit-identical eps: %d; all seeds bit-identical: %d / %d"
+          % (big.size, same_big, int((got == want).sum()), seeds.size))
+    assert same_big >= 0.9 * big.size
