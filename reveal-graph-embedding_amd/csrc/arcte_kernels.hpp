@@ -767,6 +767,13 @@ __global__ void k_keys_to_csr(const uint64_t *keys, int64_t nkeys, int64_t n, in
     }
 }
 
+// work-order keys: seeds with a big row first (their first push and their threshold pass walk the whole row)
+__global__ void k_front_keys(uint64_t *keys, const int32_t *pos, int64_t npos)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < npos) keys[pos[i]] = 0;
+}
+
 // in_degree[indices[k]] for every stored edge
 __global__ void k_edge_in_degree(const int32_t *indices, const double *in_degree, double *out, int64_t nnz)
 {
