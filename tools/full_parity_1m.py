@@ -9,19 +9,21 @@ from reveal_graph_embedding_amd.synthetic import rmat_graph
 from reveal_graph_embedding_amd.eps_randomwalk.transition import get_natural_random_walk_matrix
 from reveal_graph_embedding_amd.embedding.arcte.arcte import seed_nodes
 
+variant = int(sys.argv[1]) if len(sys.argv) > 1 else 0      # 0 ARCTE, 1 PageRank, 2 lazy PageRank
+stride = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 A = rmat_graph(1000000, 50000000, 0)
 w, od, idg = get_natural_random_walk_matrix(A)
-seeds = np.sort(seed_nodes(A))
+seeds = np.sort(seed_nodes(A))[::stride]
 print("seeds", seeds.size, flush=True)
 t = time.time()
 with _native.Context(w.indptr, w.indices, w.data, od, idg) as ctx:
-    ctx.run_seeds(seeds, 0.1, 1e-5)
+    ctx.run_seeds(seeds, (0.1 * 0.5) / (1 - 0.5 * 0.1) if variant == 2 else 0.1, 1e-5, variant=variant)
     colptr, rows, nop = ctx.fetch(want_nop=True)
     st = ctx.stats()
 print("hip %.1f s, rows %d" % (time.time() - t, rows.size), flush=True)
 t = time.time()
 o_colptr, o_rows, _, o_nop, o_stats = oracle.worker(w, od, idg, seeds, 0.1, 1e-5,
-                                                    threads=oracle.lib().oracle_max_threads(), want_stats=True)
+                                                    threads=oracle.lib().oracle_max_threads(), want_stats=True, variant=variant)
 print("oracle %.1f s" % (time.time() - t), flush=True)
 assert np.array_equal(colptr, o_colptr), "community sizes differ"
 assert np.array_equal(nop, o_nop), "push counts differ"
@@ -30,5 +32,5 @@ assert [st[k] for k in ("pushes", "edges", "enqueues", "support")] == list(o_sta
 seg = np.repeat(np.arange(seeds.size, dtype=np.int64), np.diff(colptr))
 order = np.lexsort((rows, seg))
 assert np.array_equal(rows[order], o_rows), "community members differ"
-print("IDENTICAL: %d seeds, %d emitted rows, sha256(rows) %s" % (seeds.size, rows.size,
+print("variant %d IDENTICAL: %d seeds, %d emitted rows, sha256(rows) %s" % (variant, seeds.size, rows.size,
       hashlib.sha256(o_rows.tobytes()).hexdigest()[:16]), flush=True)
