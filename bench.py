@@ -246,7 +246,7 @@ def main():
                 "pcie_inclusive_seeds_per_s_rank0": shard.size / ((elapsed / max(args.steps, 1)) + fetch_ms * 1e-3),
             },
             "roofline": {
-                "bound": "hbm", "kernel": "k_arcte_seeds<0>",
+                "bound": "hbm", "kernel": "k_arcte_seeds<0, %d, %s, 2>" % (variant, "float" if args.float32 else "double"),
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
                 "algorithmic_bytes_per_launch": alg, "kernel_ms_per_launch": kernel_ms,
