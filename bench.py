@@ -6,14 +6,13 @@
 N > 1 is launched by torch.distributed.run (one rank per GPU, backend nccl = RCCL).
 
 Workload (BASELINE.json metric: "seed-vertices/sec ... 1M-node power-law graph", configs[2]/[3]):
-R-MAT n=1,000,000 / 50,000,000 sampled edges (SURVEY.md 8(d) recipe), rho=0.1, eps=1e-5, float64.
-The reference's degree-descending seed list is dealt round-robin into `--shards` (default 8) shards
-exactly as the reference deals it over processes (arcte.py:14-23); rank r of N runs shard r.  One
-STEP = one pass of the whole hot path (effective epsilon -> exact-FIFO eps-push -> community
-extraction -> column-compressed result in HBM) over that shard, inputs resident in HBM, plus -- for
-N > 1 -- the gather of every rank's result on rank 0 over RCCL.  Per-GPU work is fixed as N grows
-("weak"); at N = 8 the step covers every seed of the graph (configs[3]).  `--shards 1` at N = 1 is the
-all-seeds pass of configs[2].
+R-MAT n=1,000,000 / 50,000,000 sampled edges (SURVEY.md 8(d) recipe), rho=0.1, eps=1e-5, float64, ALL
+651 465 seeds.  The reference's degree-descending seed list is dealt round-robin over the N ranks exactly as
+the reference deals it over processes (arcte.py:14-23): rank r of N runs seeds[r::N].  One STEP = one pass of
+the whole hot path (effective epsilon -> exact-FIFO eps-push -> community extraction -> column-compressed
+result in HBM) over every seed of the graph, inputs resident in HBM, plus -- for N > 1 -- the gather of every
+rank's result on rank 0 over RCCL.  Total work is fixed as N grows ("strong"): N = 1 is configs[2], N = 8 is
+configs[3].  `--shards S` (S > N) runs only shards 0..N-1 of S (a shorter step for profiling passes).
 
 Rank 0 prints ONE JSON line; `roofline` prices the dominant kernel (k_arcte_seeds) by ALGORITHMIC
 bytes (52 B/edge + 36 B/push + 4 B/enqueue + 36 B/support entry, counted by the
@@ -33,6 +32,17 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+KERNEL_SOURCES = ("reveal-graph-embedding_amd/csrc/arcte_kernels.hpp", "reveal-graph-embedding_amd/csrc/arcte_hip.hip")
+
+
+def kernel_source_id():
+    """Identifies the kernel a PMC measurement belongs to (the GPU box has no .git): hash of the device sources."""
+    import hashlib
+    h = hashlib.sha256()
+    for rel in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
 
 
 def log(*a):
@@ -78,8 +88,12 @@ def cpu_baseline(w, out_degree, in_degree, shard, rho, eps, budget_s):
         count = int(min(shard.size, count * min(max(budget_s / dt, 2.0), 16.0)))
     st = dict(pushes=int(stats[0]), edges=int(stats[1]), enqueues=int(stats[2]), support=int(stats[3]))
     return {"value": count / dt, "unit": "seeds/s", "cores": cores, "kind": "port",
-            "sample": "%d seeds drawn uniformly from the step's shard, %.1f s, OpenMP over seeds" % (count, dt),
-            "algorithmic_GBps": algorithmic_bytes(st) / dt / 1e9}
+            "sample": "%d seeds drawn uniformly from the step's seeds, %.1f s, OpenMP over seeds" % (count, dt),
+            "algorithmic_GBps": algorithmic_bytes(st) / dt / 1e9,
+            # how the C port relates to the reference's own Python path, measured in the build container on
+            # identical inputs (BASELINE.md / DESIGN.md section 5; the reference cannot travel to the GPU box)
+            "port_vs_reference": {"ba20000_m10_1_thread": 52, "rmat100k_2M_8_threads": 11, "unit": "x faster than the reference",
+                                  "where": "build container, 8-core Xeon 2.1 GHz"}}
 
 
 def main():
@@ -89,7 +103,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--nodes", type=int, default=1000000)
     ap.add_argument("--edges", type=int, default=50000000)
-    ap.add_argument("--shards", type=int, default=8, help="round-robin shards of the seed list; rank r runs shard r")
+    ap.add_argument("--shards", type=int, default=0,
+                    help="round-robin shards of the seed list, rank r runs shard r (default 0 = one shard per GPU: every seed)")
     ap.add_argument("--rho", type=float, default=0.1)
     ap.add_argument("--epsilon", type=float, default=1e-5)
     ap.add_argument("--slots", type=int, default=0)
@@ -111,6 +126,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)" % (args.gpus, world))
+    if args.shards <= 0:
+        args.shards = world
     if args.shards < world:
         raise SystemExit("--shards must be >= the number of GPUs")
     if not torch.cuda.is_available():
@@ -203,16 +220,23 @@ def main():
         alg = algorithmic_bytes(st)
         kernel_ms = push_ms / max(args.steps, 1)
         achieved = alg / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        # HBM bytes per launch from the PMC passes (tools/rocprof_passes.sh): only when they were taken from THIS
+        # kernel source on this workload; a stale measurement is dropped, never reported
         traffic = None
+        traffic_note = "no PMC measurement of this kernel source on this workload"
         pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc_path) and args.variant == "arcte" and not args.float32:
             try:
                 pmc = json.load(open(pmc_path))
-                key = "n%d_m%d_shards%d" % (args.nodes, args.edges, args.shards)
-                if key in pmc:
+                key = "n%d_m%d_shards%d_of_%d" % (args.nodes, args.edges, world, args.shards)
+                if key in pmc and pmc[key].get("kernel_source_id") == kernel_source_id():
                     traffic = pmc[key]["hbm_bytes_per_launch"]
+                    traffic_note = "FETCH_SIZE + WRITE_SIZE of %s, commit %s" % (pmc[key].get("source"), pmc[key].get("commit"))
+                elif key in pmc:
+                    traffic_note = "stale: measured at kernel source %s, running %s" % (pmc[key].get("kernel_source_id"), kernel_source_id())
             except Exception:
                 traffic = None
+        stream_read, stream_copy = _native.stream_bandwidth(gpu)
         result = {
             "metric": "seed-vertices/sec",
             "value": seeds_per_step * args.steps / elapsed,
@@ -222,21 +246,27 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / max(args.steps, 1) * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if args.shards == world else "weak",
             "vs_baseline": None,
             "dtype": "f32" if args.float32 else "f64",
             "data": "synthetic",
             "config": {
-                "workload": "R-MAT n=%d m=%d (nnz %d, %d seeds), rho=%g eps=%g; step = seed shard %s of %d (round-robin "
-                            "over the degree-descending seed list) per GPU through eps_eff -> eps-push -> extraction%s"
+                "workload": "R-MAT n=%d m=%d (nnz %d, %d seeds), rho=%g eps=%g; step = %s through eps_eff -> eps-push -> "
+                            "extraction%s"
                             % (args.nodes, args.edges, nnz, seeds.size, args.rho, args.epsilon,
-                               "r" if world > 1 else "0", args.shards,
+                               ("all %d seeds" % seeds.size + (", dealt round-robin over the degree-descending seed list, "
+                                                              "rank r runs seeds[r::%d]" % world if world > 1 else ""))
+                               if args.shards == world else
+                               "seed shard %s of %d (round-robin over the degree-descending seed list) per GPU" % (
+                                   "r" if world > 1 else "0", args.shards),
                                " + %s gather of %s on rank 0" % ("RCCL" if args.backend == "nccl" else "gloo (rehearsal)",
                                                                   args.gather) if world > 1 else ""),
                 "variant": args.variant,
                 "seeds_per_step": seeds_per_step,
                 "shards": args.shards,
-                "slots_per_gpu": info["slots"],
+                "slots_per_gpu": info["slots"], "waves_per_cu": info["waves_per_cu"],
+                "hot_values_per_wave": info["hot_values_per_wave"],
+                "kernel_source_id": kernel_source_id(),
                 "emitted_rows_rank0": int(total_rows),
                 "gathered_rows_rank0": int(gathered_rows),
                 "per_seed": {k: st[k] / max(shard.size, 1) for k in ("pushes", "edges", "enqueues", "support")},
@@ -246,9 +276,13 @@ def main():
                 "pcie_inclusive_seeds_per_s_rank0": shard.size / ((elapsed / max(args.steps, 1)) + fetch_ms * 1e-3),
             },
             "roofline": {
-                "bound": "hbm", "kernel": "k_arcte_seeds<0, %d, %s, 2>" % (variant, "float" if args.float32 else "double"),
+                "bound": "hbm", "kernel": "k_arcte_seeds<0, %d, %s, %d, %s>" % (variant, "float" if args.float32 else "double", info["tiles"],
+                                                                "true" if info["hot_values_per_wave"] else "false"),
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic,
+                "traffic": traffic, "traffic_note": traffic_note,
+                "measured_stream_peak": {"read_GBps": stream_read, "copy_GBps": stream_copy,
+                                         "frac_of_read": achieved / stream_read if stream_read > 0 else None,
+                                         "how": "arcte_hip_stream_bandwidth: 16 B/lane sweep over 4 GiB on this box, best of 3"},
                 "algorithmic_bytes_per_launch": alg, "kernel_ms_per_launch": kernel_ms,
             },
         }

@@ -49,9 +49,12 @@ int arcte_hip_device_count(int *count);
  * (eps_randomwalk/transition.py:43-99) and what arcte_worker receives
  * (embedding/arcte/arcte.py:279-286): CSR (indptr[n+1], indices[nnz] ascending inside a
  * row, data[nnz]) of W = D_out^-1 A, weighted out_degree[n], in_degree[n].
- * n_slots = 0 picks one slot per resident wavefront; queue_capacity = 0 picks
- * max(n, 4096) rounded up to a power of two (the FIFO of similarity.py:180 is
- * unbounded; an overflowing seed is re-run with a larger ring, never dropped).
+ * A slot is the scratch of one wavefront (one seed in flight): n_slots = 0 picks 4 wavefronts per compute unit
+ * (ARCTE_HIP_WAVES_PER_CU overrides), fewer when the dense per-slot state would not fit 3/4 of the free memory;
+ * the CU's LDS is divided among its resident wavefronts for the hot table.  queue_capacity = 0 picks
+ * min(2^20, max(4096, n/16 rounded up to a power of two)) ring entries (the FIFO of similarity.py:180 is
+ * unbounded; an overflowing seed is re-run with a 4x larger ring, never dropped).  A row that stores the same
+ * column twice is rejected with ARCTE_HIP_EINVAL (scipy's sum_duplicates() removes such entries).
  */
 int arcte_hip_create(int device, int64_t n, int64_t nnz,
                      const int64_t *indptr, const int32_t *indices, const double *data,
@@ -185,9 +188,18 @@ int arcte_hip_push_variant(int device, int64_t n, double *s, double *r,
  */
 int arcte_hip_set_float32(arcte_hip_ctx *ctx, int enable);
 
+/*
+ * Measurement helper (no counterpart in the reference; SURVEY.md 8(d) asks for the on-box streaming rate beside
+ * the 8 TB/s spec figure): the rate of a coalesced 16-byte-per-lane read sweep and of a copy (read + write bytes)
+ * over `bytes` of device memory, in GB/s, best of three.
+ */
+int arcte_hip_stream_bandwidth(int device, int64_t bytes, double *read_gbps, double *copy_gbps);
+
 /* Properties of the context: info[0] slots, [1] queue capacity, [2] device bytes held,
- * [3] compute units, [4] wavefronts per workgroup. */
-int arcte_hip_info(arcte_hip_ctx *ctx, int64_t info[5]);
+ * [3] compute units, [4] wavefronts per workgroup of the propagation kernel, [5] values of the LDS-resident hot
+ * table per wavefront (0 = table off), [6] 64-edge tiles per push iteration, [7] wavefronts per compute unit the
+ * LDS is divided among. */
+int arcte_hip_info(arcte_hip_ctx *ctx, int64_t info[8]);
 
 #ifdef __cplusplus
 }

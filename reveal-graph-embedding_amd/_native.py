@@ -45,6 +45,7 @@ SIGNATURES = {
                                          C.c_int, C.c_double]),
     "arcte_hip_push": (C.c_int, [C.c_int, C.c_int64, _f64p, _f64p, _f64p, _i32p, C.c_int64, C.c_int64, C.c_double]),
     "arcte_hip_set_float32": (C.c_int, [C.c_void_p, C.c_int]),
+    "arcte_hip_stream_bandwidth": (C.c_int, [C.c_int, C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "arcte_hip_info": (C.c_int, [C.c_void_p, _i64p]),
 }
 
@@ -89,6 +90,13 @@ def device_count():
     n = C.c_int(0)
     _check(lib().arcte_hip_device_count(C.byref(n)))
     return n.value
+
+
+def stream_bandwidth(device=0, nbytes=4 << 30):
+    """On-box streaming rates in GB/s: (coalesced read sweep, copy counted as read + write bytes)."""
+    rd, cp = C.c_double(0), C.c_double(0)
+    _check(lib().arcte_hip_stream_bandwidth(int(device), int(nbytes), C.byref(rd), C.byref(cp)))
+    return rd.value, cp.value
 
 
 class Context:
@@ -203,10 +211,11 @@ class Context:
         return dict(eps_ms=float(t[0]), push_ms=float(t[1]), compact_ms=float(t[2]), call_ms=float(t[3]))
 
     def info(self):
-        i = np.zeros(5, dtype=np.int64)
+        i = np.zeros(8, dtype=np.int64)
         _check(lib().arcte_hip_info(self._h, i))
         return dict(slots=int(i[0]), queue_capacity=int(i[1]), device_bytes=int(i[2]), compute_units=int(i[3]),
-                    waves_per_workgroup=int(i[4]))
+                    waves_per_workgroup=int(i[4]), hot_values_per_wave=int(i[5]), tiles=int(i[6]),
+                    waves_per_cu=int(i[7]))
 
     def similarity_slice(self, seed, rho, epsilon, s, r, variant=ARCTE, laziness_factor=0.5):
         if s.dtype != np.float64 or r.dtype != np.float64 or not s.flags.c_contiguous or not r.flags.c_contiguous:

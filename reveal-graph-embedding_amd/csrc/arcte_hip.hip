@@ -140,7 +140,14 @@ struct arcte_hip_ctx {
     uint32_t qcap = 0;
     DevBuf<Entry> state;
     DevBuf<uint32_t> slot_epoch;
-    DevBuf<int32_t> queue, sup;
+    DevBuf<QEntry> queue;
+    DevBuf<int32_t> sup;
+    // hot table (LDS-resident state of the highest-degree nodes) and the launch shape that goes with it
+    DevBuf<uint16_t> node_hot, edge_hot;
+    int64_t hot_ranked = 0;      // nodes that carry a rank (<= HOT_NONE)
+    int waves_per_block = 1;     // wavefronts per workgroup of k_arcte_seeds
+    int waves_per_cu = 0;        // resident wavefronts per CU the slot count was sized for
+    int tiles = 2;               // 64-edge tiles per push iteration
     uint64_t seeds_since_clear = 0;
     std::vector<int32_t> row_len;   // host copy of the row lengths: the work order is heaviest seed first
     // per-run
@@ -179,6 +186,7 @@ struct arcte_hip_ctx {
     size_t device_bytes() const
     {
         return indptr.bytes() + indices.bytes() + data.bytes() + out_degree.bytes() + in_degree.bytes() + edge_in_degree.bytes() + data_f.bytes() + in_degree_f.bytes() + edge_in_degree_f.bytes() + state.bytes() + slot_epoch.bytes() +
+               node_hot.bytes() + edge_hot.bytes() +
                queue.bytes() + sup.bytes() + seeds_d.bytes() + work_pos.bytes() + out_cnt.bytes() + status.bytes() +
                nop_d.bytes() + eps_d.bytes() + out_off.bytes() + dst_off.bytes() + raw.bytes() + rows_final.bytes();
     }
@@ -207,8 +215,9 @@ int grow_queue(arcte_hip_ctx *c)
     uint32_t nq = c->qcap * 4;
     // keep the footprint bounded: fewer, deeper slots once rings get large
     int64_t slots = c->slots;
-    while (slots > WAVES_PER_BLOCK && (size_t)slots * nq * sizeof(int32_t) > ((size_t)8 << 30)) slots /= 2;
-    slots = std::max<int64_t>(WAVES_PER_BLOCK, slots - slots % WAVES_PER_BLOCK);
+    const int wpb = c->waves_per_block;
+    while (slots > wpb && (size_t)slots * nq * sizeof(QEntry) > ((size_t)16 << 30)) slots /= 2;
+    slots = std::max<int64_t>(wpb, slots - slots % wpb);
     c->queue.release();
     if (slots != c->slots) {
         c->state.release();
@@ -221,18 +230,60 @@ int grow_queue(arcte_hip_ctx *c)
     return 0;
 }
 
-template <int MODE, int VAR, typename T>
-int launch_seeds_v(arcte_hip_ctx *c, const PushParams &P, int64_t nwork)
+constexpr size_t LDS_PER_CU = 160 * 1024;     // gfx950
+
+int env_int(const char *name, int fallback)
 {
-    int64_t waves = std::min<int64_t>(c->slots, std::max<int64_t>(nwork, 1));
-    int blocks = (int)((waves + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
-    // MODE 1 works on the dense vectors the host placed in slot 0: exactly one wavefront may run
-    const int threads = (MODE == 1) ? WAVE : BLOCK;
-    if (MODE == 1) blocks = 1;
-    // 2 x 64 edges per iteration; 4 x 64 measured the same at every slot count (124 instead of 103 VGPRs)
-    hipLaunchKernelGGL((k_arcte_seeds<MODE, VAR, T, 2>), dim3(blocks), dim3(threads), 0, c->stream, P);
+    if (const char *e = getenv(name)) {
+        char *end = nullptr;
+        long v = strtol(e, &end, 10);
+        if (end != e) return (int)v;
+    }
+    return fallback;
+}
+
+// Values of the LDS-resident hot table per wavefront: the CU's LDS divided by the wavefronts resident on it
+// (1 KiB allocation granularity), never more than there are ranked nodes.  ARCTE_HIP_HOT=0 switches the table
+// off (A/B), any other number caps it.
+uint32_t hot_values_per_wave(const arcte_hip_ctx *c, size_t value_bytes)
+{
+    const int cap = env_int("ARCTE_HIP_HOT", -1);
+    if (cap == 0 || c->hot_ranked <= 0 || c->waves_per_cu <= 0) return 0;
+    size_t per_wave = LDS_PER_CU / (size_t)c->waves_per_cu;
+    per_wave = per_wave / 1024 * 1024;
+    uint64_t k = per_wave / value_bytes;
+    k = std::min<uint64_t>(k, (uint64_t)c->hot_ranked);
+    if (cap > 0) k = std::min<uint64_t>(k, (uint64_t)cap);
+    return (uint32_t)(k - k % 4);
+}
+
+template <typename K>
+int launch_with_lds(K kernel, int blocks, int threads, size_t lds, hipStream_t stream, const PushParams &P)
+{
+    if (lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(threads), lds, stream, P);
     HIP_TRY(hipGetLastError());
     return 0;
+}
+
+template <int MODE, int VAR, typename T>
+int launch_seeds_v(arcte_hip_ctx *c, PushParams P, int64_t nwork)
+{
+    P.edge_hot = c->edge_hot.p;
+    P.node_hot = c->node_hot.p;
+    P.hotK = 0;
+    if (MODE == 1) {
+        // works on the dense vectors the host placed in slot 0: exactly one wavefront may run, all state in HBM
+        return launch_with_lds(k_arcte_seeds<MODE, VAR, T, 2, false>, 1, WAVE, 0, c->stream, P);
+    }
+    const int wpb = c->waves_per_block;
+    const int64_t waves = std::min<int64_t>(c->slots, std::max<int64_t>(nwork, 1));
+    const int blocks = (int)((waves + wpb - 1) / wpb);
+    P.hotK = hot_values_per_wave(c, sizeof(T));
+    const size_t lds = (size_t)wpb * P.hotK * sizeof(T);
+    if (P.hotK == 0) return launch_with_lds(k_arcte_seeds<MODE, VAR, T, 2, false>, blocks, wpb * WAVE, 0, c->stream, P);
+    if (c->tiles == 4) return launch_with_lds(k_arcte_seeds<MODE, VAR, T, 4, true>, blocks, wpb * WAVE, lds, c->stream, P);
+    return launch_with_lds(k_arcte_seeds<MODE, VAR, T, 2, true>, blocks, wpb * WAVE, lds, c->stream, P);
 }
 
 template <int MODE, typename T>
@@ -280,7 +331,7 @@ int launch_seeds(arcte_hip_ctx *c, const PushParams &P, int64_t nwork, int varia
 
 extern "C" {
 
-int arcte_hip_abi_version(void) { return 5; }
+int arcte_hip_abi_version(void) { return 6; }
 
 const char *arcte_hip_last_error(void) { return g_err.c_str(); }
 
@@ -311,6 +362,17 @@ int arcte_hip_create(int device, int64_t n, int64_t nnz, const int64_t *indptr, 
         if (indptr[i + 1] < indptr[i]) return fail(ARCTE_HIP_EINVAL, "indptr is not monotone");
     for (int64_t k = 0; k < nnz; k++)
         if (indices[k] < 0 || indices[k] >= n) return fail(ARCTE_HIP_EINVAL, "column index out of range");
+    {
+        // the lanes of a push own one target each (push.py:62-64 on a CSR row): a column stored twice in a row
+        // would race; scipy's sum_duplicates() (or get_natural_random_walk_matrix) removes them
+        std::vector<int64_t> last_row((size_t)n, -1);
+        for (int64_t i = 0; i < n; i++)
+            for (int64_t k = indptr[i]; k < indptr[i + 1]; k++) {
+                if (last_row[(size_t)indices[k]] == i)
+                    return fail(ARCTE_HIP_EINVAL, "row " + std::to_string(i) + " stores column " + std::to_string(indices[k]) + " twice");
+                last_row[(size_t)indices[k]] = i;
+            }
+    }
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
     if (device < 0 || device >= ndev) return fail(ARCTE_HIP_EHIP, "no such HIP device");
@@ -346,22 +408,59 @@ int arcte_hip_create(int device, int64_t n, int64_t nnz, const int64_t *indptr, 
             HIP_TRY(hipGetLastError());
         }
         HIP_TRY(c->counters.alloc(8));
+        // ---- hot table: rank the nodes by pattern in-degree (stable: ties keep the node order), the ranks stream
+        //      with the rows.  All on the device; the host never sees the ranking.
+        {
+            const int64_t ranked = std::min<int64_t>(n, (int64_t)HOT_NONE);
+            HIP_TRY(c->node_hot.alloc(n));
+            HIP_TRY(c->edge_hot.alloc(nnz));
+            HIP_TRY(hipMemsetAsync(c->node_hot.p, 0xFF, c->node_hot.bytes(), c->stream));
+            DevBuf<uint32_t> cnt, keys_in, keys_out;
+            DevBuf<int32_t> ids_in, ids_out;
+            DevBuf<char> temp;
+            int rk = [&]() -> int {
+                HIP_TRY(cnt.alloc(n));
+                HIP_TRY(keys_in.alloc(n));
+                HIP_TRY(keys_out.alloc(n));
+                HIP_TRY(ids_in.alloc(n));
+                HIP_TRY(ids_out.alloc(n));
+                HIP_TRY(hipMemsetAsync(cnt.p, 0, cnt.bytes(), c->stream));
+                const int tb = 256;
+                if (nnz) hipLaunchKernelGGL(k_column_counts, dim3((unsigned)((nnz + tb - 1) / tb)), dim3(tb), 0, c->stream, c->indices.p, nnz, cnt.p);
+                hipLaunchKernelGGL(k_rank_keys, dim3((unsigned)((n + tb - 1) / tb)), dim3(tb), 0, c->stream, cnt.p, n, keys_in.p, ids_in.p);
+                HIP_TRY(hipGetLastError());
+                size_t temp_bytes = 0;
+                HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, keys_in.p, keys_out.p, ids_in.p, ids_out.p, (int)n, 0, 32, c->stream));
+                HIP_TRY(temp.alloc(temp_bytes));
+                HIP_TRY(hipcub::DeviceRadixSort::SortPairs(temp.p, temp_bytes, keys_in.p, keys_out.p, ids_in.p, ids_out.p, (int)n, 0, 32, c->stream));
+                hipLaunchKernelGGL(k_assign_hot, dim3((unsigned)((ranked + tb - 1) / tb)), dim3(tb), 0, c->stream, ids_out.p, ranked, c->node_hot.p);
+                if (nnz) hipLaunchKernelGGL(k_edge_hot, dim3((unsigned)((nnz + tb - 1) / tb)), dim3(tb), 0, c->stream, c->indices.p, c->node_hot.p, c->edge_hot.p, nnz);
+                HIP_TRY(hipGetLastError());
+                HIP_TRY(hipStreamSynchronize(c->stream));
+                return 0;
+            }();
+            cnt.release(); keys_in.release(); keys_out.release(); ids_in.release(); ids_out.release(); temp.release();
+            if (rk) return rk;
+            c->hot_ranked = ranked;
+        }
+        // ---- launch shape.  The propagation kernel is bound by the chip's random-access rate into the per-slot HBM
+        //      state, and the LDS-resident hot table takes 20-40 % of those accesses away -- the more the fewer
+        //      wavefronts share a CU's LDS, while fewer wavefronts keep fewer accesses in flight.
+        c->waves_per_block = std::max(1, std::min(env_int("ARCTE_HIP_WAVES_PER_BLOCK", 1), WAVES_PER_BLOCK));
+        c->tiles = env_int("ARCTE_HIP_TILES", 2) == 4 ? 4 : 2;
+        const int wpb = c->waves_per_block;
         int64_t slots = n_slots;
         if (slots <= 0) {
-            int per_cu = 0;
-            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (k_arcte_seeds<0, 0, double, 2>), BLOCK, 0));
-            // 2 workgroups (8 wavefronts) per CU already sit on the random-write wall (slot sweeps on the 1M/50M
-            // graph: 22.4-22.7 G edges/s from 2048 to 4096 slots, ~600 k seeds/s already at 1024); more slots only
-            // add footprint
-            per_cu = std::max(1, std::min(per_cu, 2));
-            slots = (int64_t)per_cu * c->cus * WAVES_PER_BLOCK;
+            c->waves_per_cu = std::max(1, std::min(env_int("ARCTE_HIP_WAVES_PER_CU", 4), 32));
+            slots = (int64_t)c->waves_per_cu * c->cus;
             // keep the slot scratch within a fixed share of the device
             size_t free_b = 0, total_b = 0;
             HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-            size_t per_slot = (size_t)n * (sizeof(Entry) + sizeof(int32_t)) + (size_t)default_queue_capacity(n) * 4;
-            while (slots > WAVES_PER_BLOCK && (size_t)slots * per_slot > free_b / 4 * 3) slots -= WAVES_PER_BLOCK * c->cus / 4;
+            size_t per_slot = (size_t)n * (sizeof(Entry) + sizeof(int32_t)) + (size_t)default_queue_capacity(n) * sizeof(QEntry);
+            while (slots > c->cus && (size_t)slots * per_slot > free_b / 4 * 3) slots -= c->cus / 2;
         }
-        slots = std::max<int64_t>(WAVES_PER_BLOCK, (slots + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK * WAVES_PER_BLOCK);
+        slots = std::max<int64_t>(wpb, (slots + wpb - 1) / wpb * wpb);
+        c->waves_per_cu = (int)std::max<int64_t>(1, std::min<int64_t>(32, (slots + c->cus - 1) / c->cus));
         uint32_t qcap = queue_capacity > 0 ? next_pow2((uint64_t)queue_capacity) : default_queue_capacity(n);
         if (qcap < (uint32_t)WAVE) qcap = WAVE;
         int r = alloc_slots(c, slots, qcap);
@@ -385,7 +484,7 @@ int arcte_hip_destroy(arcte_hip_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     c->indptr.release(); c->indices.release(); c->data.release(); c->out_degree.release(); c->in_degree.release();
-    c->state.release(); c->slot_epoch.release(); c->edge_in_degree.release(); c->data_f.release(); c->in_degree_f.release(); c->edge_in_degree_f.release(); c->queue.release(); c->sup.release();
+    c->state.release(); c->slot_epoch.release(); c->node_hot.release(); c->edge_hot.release(); c->edge_in_degree.release(); c->data_f.release(); c->in_degree_f.release(); c->edge_in_degree_f.release(); c->queue.release(); c->sup.release();
     c->seeds_d.release(); c->work_pos.release(); c->out_cnt.release(); c->status.release(); c->nop_d.release();
     c->eps_d.release(); c->out_off.release(); c->dst_off.release(); c->counters.release();
     c->raw.release(); c->rows_final.release(); c->sort_keys.release(); c->sort_iota.release(); c->sort_temp.release(); c->eps_big_pos.release(); c->sort_keys_in.release();
@@ -1011,6 +1110,52 @@ int arcte_hip_push_variant(int device, int64_t n, double *s, double *r, const do
     return push_impl(device, n, s, r, w_i, a_i, deg, push_node, rho, variant, laziness_factor);
 }
 
+int arcte_hip_stream_bandwidth(int device, int64_t bytes, double *read_gbps, double *copy_gbps)
+{
+    if (bytes < (1 << 20) || !read_gbps || !copy_gbps) return fail(ARCTE_HIP_EINVAL, "bad argument");
+    HIP_TRY(hipSetDevice(device));
+    const int64_t n16 = bytes / 16;
+    DevBuf<uint4> a, b;
+    DevBuf<unsigned long long> sink;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = [&]() -> int {
+        HIP_TRY(a.alloc(n16));
+        HIP_TRY(b.alloc(n16));
+        HIP_TRY(sink.alloc(1));
+        HIP_TRY(hipMemset(a.p, 1, a.bytes()));
+        HIP_TRY(hipMemset(b.p, 0, b.bytes()));
+        HIP_TRY(hipEventCreate(&e0));
+        HIP_TRY(hipEventCreate(&e1));
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, device));
+        const int blocks = prop.multiProcessorCount * 8;
+        double best_r = 0, best_c = 0;
+        for (int rep = 0; rep < 4; rep++) {
+            float ms = 0;
+            HIP_TRY(hipEventRecord(e0, 0));
+            hipLaunchKernelGGL(k_stream_read, dim3(blocks), dim3(256), 0, 0, a.p, n16, sink.p);
+            HIP_TRY(hipEventRecord(e1, 0));
+            HIP_TRY(hipEventSynchronize(e1));
+            HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+            if (rep) best_r = std::max(best_r, (double)n16 * 16 / (ms * 1e-3) / 1e9);
+            HIP_TRY(hipEventRecord(e0, 0));
+            hipLaunchKernelGGL(k_stream_copy, dim3(blocks), dim3(256), 0, 0, a.p, b.p, n16);
+            HIP_TRY(hipEventRecord(e1, 0));
+            HIP_TRY(hipEventSynchronize(e1));
+            HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+            if (rep) best_c = std::max(best_c, (double)n16 * 32 / (ms * 1e-3) / 1e9);
+        }
+        HIP_TRY(hipGetLastError());
+        *read_gbps = best_r;
+        *copy_gbps = best_c;
+        return 0;
+    }();
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    a.release(); b.release(); sink.release();
+    return rc;
+}
+
 int arcte_hip_set_float32(arcte_hip_ctx *c, int enable)
 {
     if (!c) return fail(ARCTE_HIP_EINVAL, "ctx is NULL");
@@ -1018,14 +1163,17 @@ int arcte_hip_set_float32(arcte_hip_ctx *c, int enable)
     return 0;
 }
 
-int arcte_hip_info(arcte_hip_ctx *c, int64_t info[5])
+int arcte_hip_info(arcte_hip_ctx *c, int64_t info[8])
 {
     if (!c || !info) return fail(ARCTE_HIP_EINVAL, "bad argument");
     info[0] = c->slots;
     info[1] = c->qcap;
     info[2] = (int64_t)c->device_bytes();
     info[3] = c->cus;
-    info[4] = WAVES_PER_BLOCK;
+    info[4] = c->waves_per_block;
+    info[5] = hot_values_per_wave(c, c->float32 ? sizeof(float) : sizeof(double));
+    info[6] = c->tiles;
+    info[7] = c->waves_per_cu;
     return 0;
 }
 

@@ -314,8 +314,32 @@ template <typename T> __device__ __forceinline__ T cand_margin();
 template <> __device__ __forceinline__ double cand_margin<double>() { return 1.0 - 0x1p-40; }
 template <> __device__ __forceinline__ float cand_margin<float>() { return 1.0f - 0x1p-16f; }
 
+// Ring entry of the per-seed FIFO (similarity.py:180): the node, its index in the LDS-resident hot table
+// (HOT_NONE when it has none) and its in_degree, all known when the node is enqueued, so a pop needs one
+// 16-byte load before it can test r/in_degree.
+struct __attribute__((aligned(16))) QEntry {
+    int32_t v;
+    uint32_t h;
+    double d;
+};
+static_assert(sizeof(QEntry) == 16, "QEntry must be 16 bytes");
+constexpr uint32_t HOT_NONE = 0xFFFFu;
+
+// Sentinel of the hot table: "this node's state has moved to the dense HBM state" (it was pushed, or it is the
+// seed).  A NaN with a payload no arithmetic on finite inputs produces.
+template <typename T> __device__ __forceinline__ T hot_moved();
+template <> __device__ __forceinline__ double hot_moved<double>() { return __longlong_as_double(0x7FF8DEAD0000BEEFll); }
+template <> __device__ __forceinline__ float hot_moved<float>() { return __uint_as_float(0x7FC0BEEFu); }
+__device__ __forceinline__ bool is_moved(double x) { return __double_as_longlong(x) == 0x7FF8DEAD0000BEEFll; }
+__device__ __forceinline__ bool is_moved(float x) { return __float_as_uint(x) == 0x7FC0BEEFu; }
+
 struct PushParams {
     GraphDev g;
+    // hot table (LDS): nodes ranked by pattern in-degree; edge_hot[k] = rank of indices[k] (HOT_NONE beyond the
+    // ranked prefix), node_hot[v] likewise per node; a wavefront keeps ranks < hotK on chip
+    const uint16_t *edge_hot;
+    const uint16_t *node_hot;
+    uint32_t hotK;
     // work list
     const int32_t *work_pos;   // positions into seeds/eps/out arrays for this launch (NULL = identity)
     int64_t nwork;
@@ -328,7 +352,7 @@ struct PushParams {
     // per-slot scratch
     void *state;       // [slots][n] EntryT<T>
     uint32_t *slot_epoch;   // [slots] last epoch used by the slot
-    int32_t *queue;    // [slots][qcap]
+    QEntry *queue;     // [slots][qcap]
     int32_t *sup;      // [slots][n]   candidate list (see cand_thr)
     uint32_t qcap;     // power of two
     int32_t max_pushes; // per-seed cap, see ST_RUNAWAY
@@ -349,19 +373,29 @@ struct PushParams {
 // VAR 0: cumulative PageRank difference (push.py:41-64, similarity.py:149-222) -- ARCTE proper.
 // VAR 1: PageRank limit push (push.py:4-17, similarity.py:11-63).
 // VAR 2: lazy PageRank push (push.py:20-38, similarity.py:66-146) with its self re-push loops.
-template <int MODE, int VAR, typename T, int TILES>
+// HOT: the state of the hotK nodes of highest pattern in-degree lives in LDS, one table of hotK values per
+// wavefront, zeroed per seed -- exactly the reference's s[:] = 0; r[:] = 0 (arcte.py:337-338).  Until a node is
+// pushed its r and s are the SAME number (both receive every deposit, push.py:63-64, and only a push separates
+// them, push.py:59), so one value per node is enough (for the PageRank flavours s stays 0 until the push);
+// a node that IS pushed -- and the seed -- moves to the dense HBM state and leaves the sentinel behind.  Every
+// deposit to an on-chip node is an LDS read-modify-write instead of a random HBM one: with 2 560-5 120 values per
+// wavefront that is 20-30 % of the traversed edges of the 1M/50M graph (tools/hot_share.py).
+template <int MODE, int VAR, typename T, int TILES, bool HOT>
 __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
 {
+    extern __shared__ __attribute__((aligned(16))) unsigned char hot_raw[];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int64_t slot = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wave;
+    const int64_t slot = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave;
     const GraphDev &g = P.g;
     const GraphValues<T> gv = graph_values<T>(g);
     EntryT<T> *__restrict__ st = reinterpret_cast<EntryT<T> *>(P.state) + slot * g.n;
-    int32_t *__restrict__ q = P.queue + slot * (int64_t)P.qcap;
+    QEntry *__restrict__ q = P.queue + slot * (int64_t)P.qcap;
     int32_t *__restrict__ sup = P.sup + slot * g.n;
     const uint32_t qmask = P.qcap - 1;
     const T omr = (T)P.one_minus_rho;
+    const uint32_t K = HOT ? P.hotK : 0u;
+    T *hot = reinterpret_cast<T *>(hot_raw) + (size_t)wave * K;
     uint32_t epoch = P.slot_epoch[slot];
 
     // Dynamic seed queue: lane 0 draws the next work item, the wave broadcasts it.  The
@@ -373,6 +407,14 @@ __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
         unsigned long long w = 0;
         if (lane == 0) w = atomicAdd(P.work_counter, 1ULL);
         return bcast_u64(w);
+    };
+    // r of node u whose hot rank is h: on chip unless it has moved
+    auto read_r = [&](int32_t u, uint32_t h) -> T {
+        if (HOT && h < K) {
+            const T x = hot[h];
+            if (!is_moved(x)) return x;
+        }
+        return st[u].r;
     };
     // (the extra bound is insurance only: a wave can draw at most nwork items, so a loop that ever ran past that
     //  would be a compiler-induced divergence like the one described above, and must still terminate)
@@ -399,6 +441,10 @@ __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
             }
         }
         epoch++;                           // every entry of the previous seed is stale from here on
+        if (HOT) {
+            // s[:] = 0; r[:] = 0 for the on-chip nodes
+            for (uint32_t i = lane; i < K; i += WAVE) hot[i] = T(0);
+        }
 
         uint32_t head = 0, tail = 0;       // ring counters (wave-uniform)
         int32_t nsup = 0;          // candidates
@@ -409,10 +455,21 @@ __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
         bool ok = true, runaway = false;
 
         // ---- one push of node u (push.py:41-64) followed by the ordered enqueue of
-        //      similarity.py:194-196 / :214-216.  `ru` is r[u] at pop time.
-        auto push = [&](int32_t u, T ru, int64_t rb, int64_t re, bool do_enqueue) {
+        //      similarity.py:194-196 / :214-216.  `ru` is r[u] at pop time, `hu` u's hot rank, `du` its in_degree.
+        auto push = [&](int32_t u, uint32_t hu, T du, T ru, int64_t rb, int64_t re, bool do_enqueue) {
             T c;            // what every neighbour receives per unit of transition weight
             T r_self;       // r[u] right after the push bookkeeping (what a self-loop lane adds to)
+            // u still on chip: this push is its first, so s[u] == r[u] == ru (ARCTE) or s[u] == 0 (PageRank
+            // flavours); it moves to the HBM state now, where the code below finds it as it finds any other node
+            bool on_chip = false;
+            if (HOT && hu < K) {
+                on_chip = !is_moved(hot[hu]);
+                if (on_chip && lane == 0) {
+                    hot[hu] = hot_moved<T>();
+                    store_lo(st + u, ru, (VAR == 0) ? ru : T(0));
+                    store_hi(st + u, du, epoch);
+                }
+            }
             if (VAR == 0) {
                 c = omr * ru;                                    // push.py:56
                 r_self = T(0);
@@ -423,7 +480,7 @@ __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
                 else { c = omr * (1 - (T)P.lazy) * ru; r_self = omr * (T)P.lazy * (ru); }            // push.py:30-31
                 bool grew = false;
                 if (lane == 0) {
-                    const T s_old = st[u].s;                // u is live: it was deposited to, or is the seed
+                    const T s_old = on_chip ? T(0) : st[u].s;   // u is live: it was deposited to, or is the seed
                     const T s_new = s_old + A;              // push.py:14 / :34
                     store_lo(st + u, r_self, s_new);             // push.py:15 / :35
                     grew = s_old == T(0) && s_new != T(0);
@@ -435,40 +492,62 @@ __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
             }
             for (int64_t base = rb; base < re; base += TILES * WAVE) {
                 // TILES x 64 edges per iteration: every load of the iteration is issued before the first use
-                bool a_[TILES];
+                bool a_[TILES], chip_[TILES];
                 int32_t v_[TILES];
-                T w_[TILES], d_[TILES];
+                uint32_t hh_[TILES];
+                T w_[TILES], d_[TILES], x_[TILES];
                 LoT<T> l_[TILES];
                 HiT<T> h_[TILES];
 #pragma unroll
                 for (int t = 0; t < TILES; t++) {
                     const int64_t k = base + t * WAVE + lane;
                     a_[t] = k < re;
-                    v_[t] = 0; w_[t] = T(0); d_[t] = T(1);
-                    if (a_[t]) { v_[t] = g.indices[k]; w_[t] = gv.data[k]; d_[t] = gv.edge_in_degree[k]; }
+                    v_[t] = 0; w_[t] = T(0); d_[t] = T(1); hh_[t] = HOT_NONE;
+                    if (a_[t]) {
+                        v_[t] = g.indices[k]; w_[t] = gv.data[k]; d_[t] = gv.edge_in_degree[k];
+                        if (HOT) hh_[t] = P.edge_hot[k];
+                    }
                 }
 #pragma unroll
                 for (int t = 0; t < TILES; t++) {
                     l_[t] = {T(0), T(0)};
                     h_[t] = {T(1), 0u};
-                    if (a_[t]) { l_[t] = load_lo(st + v_[t]); h_[t] = load_hi(st + v_[t]); }
+                    chip_[t] = false;
+                    x_[t] = T(0);
+                    // nodes without a place in the table go to HBM at once, the others after a look at the table
+                    if (a_[t] && !(HOT && hh_[t] < K)) { l_[t] = load_lo(st + v_[t]); h_[t] = load_hi(st + v_[t]); }
+                }
+                if (HOT) {
+#pragma unroll
+                    for (int t = 0; t < TILES; t++) {
+                        if (a_[t] && hh_[t] < K) {
+                            x_[t] = hot[hh_[t]];
+                            chip_[t] = !is_moved(x_[t]);
+                            if (!chip_[t]) { l_[t] = load_lo(st + v_[t]); h_[t] = load_hi(st + v_[t]); }
+                        }
+                    }
                 }
 #pragma unroll
                 for (int t = 0; t < TILES; t++) {
                     const bool act = a_[t];
+                    const bool chip = HOT && chip_[t];
                     const int32_t v = v_[t];
                     const T w = w_[t];
                     const T dv = d_[t];
                     const LoT<T> lo = l_[t];
-                    const bool live = h_[t].epoch == epoch;
+                    const bool live = chip || h_[t].epoch == epoch;
                     const T p = c * w;                                  // push.py:62 / :17 / :38
-                    const T r_old = live ? ((v != u) ? lo.r : r_self) : T(0);   // a self-loop sees r[u] as just set
-                    const T s_old = live ? lo.s : T(0);
+                    // (an on-chip node is never u itself: u has just moved)
+                    const T r_old = chip ? x_[t] : (live ? ((v != u) ? lo.r : r_self) : T(0));   // a self-loop sees r[u] as just set
+                    const T s_old = chip ? ((VAR == 0) ? x_[t] : T(0)) : (live ? lo.s : T(0));
                     const T r_new = r_old + p;                          // push.py:64
                     const T s_new = (VAR == 0) ? s_old + p : s_old;     // push.py:63 (ARCTE only)
                     if (act) {
-                        store_lo(st + v, r_new, s_new);
-                        if (!live) store_hi(st + v, dv, epoch);
+                        if (chip) hot[hh_[t]] = r_new;                  // == s_new for ARCTE; s stays 0 otherwise
+                        else {
+                            store_lo(st + v, r_new, s_new);
+                            if (!live) store_hi(st + v, dv, epoch);
+                        }
                     }
                     if (VAR == 0) {
                         // Candidate list: every node whose s/in_degree has reached cand_thr, a lower bound of
@@ -488,7 +567,11 @@ __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
                     if (cnt) {
                         if (tail - head + cnt > P.qcap) { ok = false; }
                         else {
-                            if (enq) q[(tail + lane_below(me)) & qmask] = v;
+                            if (enq) {
+                                QEntry e;
+                                e.v = v; e.h = hh_[t]; e.d = (double)dv;
+                                q[(tail + lane_below(me)) & qmask] = e;
+                            }
                             tail += cnt;
                         }
                     }
@@ -509,6 +592,10 @@ __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
             else st[seed].r = T(1);                                //   (MODE 1: the caller's s[seed] stays)
             if (MODE == 0) store_hi(st + seed, seed_d, epoch);   // MODE 1: the host made every entry live
             if (VAR == 0) sup[0] = seed;
+            if (HOT) {
+                const uint32_t hs = P.node_hot[seed];
+                if (hs < K) hot[hs] = hot_moved<T>();              // the seed's state is the HBM entry just written
+            }
         }
         nsup = (VAR == 0) ? 1 : 0;
         nfirst = (VAR == 0) ? 1 : 0;
@@ -526,13 +613,13 @@ __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
             cand_thr = wave_min_real<T>(lb) * cand_margin<T>();
         }
         // (PageRank flavours: s is non-zero only at pushed nodes; the candidate list is the pushed nodes)
-        push(seed, T(1), seed_b, seed_e, true);
+        push(seed, HOT_NONE, seed_d, T(1), seed_b, seed_e, true);
         if (VAR == 2) {
             // similarity.py:108-116: re-push the seed while it stays above the threshold, no enqueue
             while (ok) {
                 const T ru2 = st[seed].r;
                 if (!(ru2 / seed_d >= eps)) break;
-                push(seed, ru2, seed_b, seed_e, false);
+                push(seed, HOT_NONE, seed_d, ru2, seed_b, seed_e, false);
             }
         }
 
@@ -545,12 +632,15 @@ __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
             const uint32_t bn = navail < (uint32_t)WAVE ? navail : (uint32_t)WAVE;
             const bool valid = (uint32_t)lane < bn;
             int32_t u_l = 0;
+            uint32_t h_l = HOT_NONE;
             T r_l = T(0), d_l = T(1);
             int64_t rb_l = 0, re_l = 0;
             if (valid) {
-                u_l = q[(head + lane) & qmask];
-                r_l = st[u_l].r;              // queued nodes were deposited to in this epoch: live
-                d_l = st[u_l].d;
+                const QEntry e = q[(head + lane) & qmask];
+                u_l = e.v;
+                h_l = e.h;
+                d_l = (T)e.d;
+                r_l = read_r(u_l, h_l);       // queued nodes were deposited to in this epoch: live
                 rb_l = g.indptr[u_l];
                 re_l = g.indptr[u_l + 1];
             }
@@ -562,13 +652,14 @@ __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
                 if (m == 0) break;
                 const int i = __ffsll((unsigned long long)m) - 1;
                 const int32_t u = __shfl(u_l, i, WAVE);
+                const uint32_t hu = (uint32_t)__shfl((int)h_l, i, WAVE);
                 const T du = shfl_real<T>(d_l, i);
                 T ru = shfl_real<T>(r_l, i);
                 consumed = i + 1;
                 if (P.refresh_failing_only) {
                     // r of a passing entry can only have grown since it was read -- unless the node was pushed in
                     // between (the queue holds duplicates): read it again, it is this entry's pop time now
-                    ru = st[u].r;
+                    ru = read_r(u, hu);
                     if (!(ru / du >= eps)) {
                         if (lane == i) pass = false;
                         continue;
@@ -576,20 +667,20 @@ __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
                 }
                 const int64_t rb = shfl_i64(rb_l, i);
                 const int64_t re = shfl_i64(re_l, i);
-                push(u, ru, rb, re, true);
+                push(u, hu, du, ru, rb, re, true);
                 if (VAR == 2) {
                     // similarity.py:136-144: re-push the same node while it stays above the threshold
                     while (ok) {
                         const T ru2 = st[u].r;
                         if (!(ru2 / du >= eps)) break;
-                        push(u, ru2, rb, re, false);
+                        push(u, hu, du, ru2, rb, re, false);
                     }
                 }
                 if (!ok) break;
                 // re-test the entries not consumed yet: all of them (every test then sees r at its pop time), or
                 // only those that did not pass (a passing entry is re-read when its turn comes)
                 if (valid && lane >= consumed && !(P.refresh_failing_only && pass)) {
-                    r_l = st[u_l].r;
+                    r_l = read_r(u_l, h_l);
                     pass = r_l / d_l >= eps;
                 }
             }
@@ -609,9 +700,21 @@ __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
             for (int64_t k = sb + lane; k < se; k += WAVE) {
                 const int32_t v = g.indices[k];
                 selfloop |= (v == seed);
-                const LoT<T> lo = load_lo(st + v);
-                const HiT<T> hi = load_hi(st + v);
-                const T sv = (hi.epoch == epoch) ? lo.s : T(0);
+                T sv = T(0);
+                bool chip = false;
+                if (HOT) {
+                    const uint32_t hv = P.edge_hot[k];
+                    if (hv < K) {
+                        const T x = hot[hv];
+                        chip = !is_moved(x);
+                        if (chip) sv = (VAR == 0) ? x : T(0);
+                    }
+                }
+                if (!chip) {
+                    const LoT<T> lo = load_lo(st + v);
+                    const HiT<T> hi = load_hi(st + v);
+                    sv = (hi.epoch == epoch) ? lo.s : T(0);
+                }
                 miss |= (sv == T(0));
                 const T x = sv / gv.edge_in_degree[k];
                 thr = (x < thr) ? x : thr;
@@ -631,7 +734,19 @@ __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
                     int32_t v = 0;
                     if (i < nsup) {
                         v = sup[i];
-                        sel = (st[v].s / st[v].d) >= thr;                 // arcte.py:363-367
+                        bool chip = false;
+                        T sv = T(0), dv = T(1);
+                        if (HOT) {
+                            const uint32_t hv = P.node_hot[v];
+                            if (hv < K) {
+                                const T x = hot[hv];
+                                chip = !is_moved(x);
+                                // (candidates of the PageRank flavours were pushed, so they are never on chip)
+                                if (chip) { sv = (VAR == 0) ? x : T(0); dv = gv.in_degree[v]; }
+                            }
+                        }
+                        if (!chip) { sv = st[v].s; dv = st[v].d; }
+                        sel = (sv / dv) >= thr;                               // arcte.py:363-367
                     }
                     const uint64_t ms = __ballot(sel);
                     if (sel) sup[cnt + lane_below(ms)] = v;               // in place: cnt <= i0
@@ -774,11 +889,56 @@ __global__ void k_front_keys(uint64_t *keys, const int32_t *pos, int64_t npos)
     if (i < npos) keys[pos[i]] = 0;
 }
 
+// ---- hot table: rank the nodes by pattern in-degree ---------------------------------------------------------
+// number of stored edges that point at each node
+__global__ void k_column_counts(const int32_t *indices, int64_t nnz, uint32_t *count)
+{
+    int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < nnz) atomicAdd(count + indices[k], 1u);
+}
+
+// sort keys: descending count (the radix sort is ascending and stable, so ties keep the node order)
+__global__ void k_rank_keys(const uint32_t *count, int64_t n, uint32_t *keys, int32_t *ids)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { keys[i] = ~count[i]; ids[i] = (int32_t)i; }
+}
+
+// node_hot[v] = rank of v when it is among the `ranked` nodes of highest count (node_hot was filled with HOT_NONE)
+__global__ void k_assign_hot(const int32_t *sorted_ids, int64_t ranked, uint16_t *node_hot)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < ranked) node_hot[sorted_ids[i]] = (uint16_t)i;
+}
+
+// the rank of every stored edge's target: streams with the row like the weight and the in_degree
+__global__ void k_edge_hot(const int32_t *indices, const uint16_t *node_hot, uint16_t *edge_hot, int64_t nnz)
+{
+    int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < nnz) edge_hot[k] = node_hot[indices[k]];
+}
+
 // in_degree[indices[k]] for every stored edge
 __global__ void k_edge_in_degree(const int32_t *indices, const double *in_degree, double *out, int64_t nnz)
 {
     int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k < nnz) out[k] = in_degree[indices[k]];
+}
+
+// ---- streaming-rate probes (bench.py reports the roofline fraction against the measured rate too) ----------
+__global__ __launch_bounds__(256) void k_stream_read(const uint4 *src, int64_t n16, unsigned long long *sink)
+{
+    uint32_t acc = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint4 v = src[i];
+        acc ^= v.x ^ v.y ^ v.z ^ v.w;
+    }
+    if (acc == 0x12345678u) atomicAdd(sink, 1ULL);
+}
+
+__global__ __launch_bounds__(256) void k_stream_copy(const uint4 *src, uint4 *dst, int64_t n16)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (int64_t)gridDim.x * blockDim.x) dst[i] = src[i];
 }
 
 // push.py:41-64 (variant 0), :4-17 (variant 1), :20-38 (variant 2) on dense device vectors, one workgroup

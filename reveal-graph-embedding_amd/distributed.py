@@ -102,19 +102,21 @@ def arcte_distributed(adjacency_matrix, rho, epsilon, device=None, group=None, r
     seeds = seed_nodes(adjacency_matrix)
     mine = shard_seeds(seeds, world, rank)
 
+    # RCCL (backend "nccl") moves device memory and wants ONE GPU per rank: resolve it before either branch, so that
+    # no rank ever parks its tensors on GPU 0 by default; gloo needs host tensors.
+    on_gpu = dist.get_backend(group) == "nccl"
+    if device is None:
+        device = int(os.environ.get("LOCAL_RANK", "0"))
+    if on_gpu:
+        torch.cuda.set_device(device)
     if run_shard is not None:
         colptr, rows = run_shard(w, out_degree, in_degree, mine, rho, epsilon)
         counts_t = torch.from_numpy(np.diff(colptr).astype(np.int64))
         rows_t = torch.from_numpy(np.ascontiguousarray(rows, dtype=np.int32))
-        if dist.get_backend(group) == "nccl":
-            counts_t, rows_t = counts_t.cuda(), rows_t.cuda()
+        if on_gpu:
+            counts_t, rows_t = counts_t.to("cuda:%d" % device), rows_t.to("cuda:%d" % device)
     else:
         from reveal_graph_embedding_amd import _native
-        if device is None:
-            device = int(os.environ.get("LOCAL_RANK", "0"))
-        on_gpu = dist.get_backend(group) == "nccl"       # RCCL moves device memory; gloo needs host tensors
-        if on_gpu:
-            torch.cuda.set_device(device)
         with _native.Context(w.indptr, w.indices, w.data, out_degree, in_degree, device=device) as ctx:
             ctx.run_seeds(mine, rho, epsilon, use_effective_epsilon=True)
             _, total = ctx.result_sizes()

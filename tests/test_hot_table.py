@@ -1,0 +1,85 @@
+"""The LDS-resident hot table of the push kernel must be invisible in the results.
+
+The state of the highest-degree nodes lives in LDS (one value per node while r == s, moved to the dense HBM state
+when the node is pushed).  Whatever the table size -- off, a handful of nodes (hot and cold targets mixed inside
+one tile), every node on chip -- communities, push counts and work counters must equal the oracle's, for the three
+push flavours and both arithmetic types (float32 against its own table-off run)."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+
+GRAPHS = ["ba300", "grid25", "corner", "weighted", "selfloop", "directed", "rmat2000", "ws1000"]
+FLAVOURS = [oracle.ARCTE, oracle.PAGERANK, oracle.LAZY_PAGERANK]
+
+
+def run(g, cap, variant, monkeypatch, float32=False, **kw):
+    from reveal_graph_embedding_amd import _native
+    monkeypatch.setenv("ARCTE_HIP_HOT", str(cap))
+    w = g["w"]
+    rho = g["rho"]
+    with _native.Context(w.indptr, w.indices, w.data, g["out_degree"], g["in_degree"], **kw) as ctx:
+        if float32:
+            ctx.set_float32(True)
+        ctx.run_seeds(g["all_seeds"], (rho * 0.5) / (1 - 0.5 * rho) if variant == oracle.LAZY_PAGERANK else rho, g["epsilon"],
+                      variant=variant, laziness_factor=0.5)
+        colptr, rows, nop = ctx.fetch(want_nop=True)
+        st = ctx.stats()
+    return colptr, rows, nop, [st["pushes"], st["edges"], st["enqueues"], st["support"]]
+
+
+def sorted_rows(colptr, rows):
+    seg = np.repeat(np.arange(colptr.size - 1), np.diff(colptr))
+    return rows[np.lexsort((rows, seg))]
+
+
+@pytest.mark.parametrize("name", GRAPHS)
+@pytest.mark.parametrize("variant", FLAVOURS)
+def test_every_table_size_matches_the_oracle(name, variant, monkeypatch):
+    g = load_golden(name)
+    w = g["w"]
+    o_colptr, o_rows, _, o_nop, o_stats = oracle.worker(w, g["out_degree"], g["in_degree"], g["all_seeds"], g["rho"],
+                                                        g["epsilon"], want_stats=True, variant=variant)
+    for cap in (0, 4, 32, -1):
+        colptr, rows, nop, stats = run(g, cap, variant, monkeypatch)
+        assert np.array_equal(colptr, o_colptr), "hot cap %d" % cap
+        assert np.array_equal(nop, o_nop), "hot cap %d" % cap
+        assert np.array_equal(sorted_rows(colptr, rows), o_rows), "hot cap %d" % cap
+        assert stats == list(o_stats), "hot cap %d" % cap
+
+
+@pytest.mark.parametrize("shape", [dict(n_slots=4), dict(n_slots=512), dict()])
+def test_launch_shapes(shape, monkeypatch):
+    """One wavefront per CU with the whole LDS, many, and the default; two wavefronts per workgroup."""
+    g = load_golden("rmat2000")
+    ref = run(g, 0, oracle.ARCTE, monkeypatch, **shape)
+    for wpb in ("1", "2", "4"):
+        monkeypatch.setenv("ARCTE_HIP_WAVES_PER_BLOCK", wpb)
+        for tiles in ("2", "4"):
+            monkeypatch.setenv("ARCTE_HIP_TILES", tiles)
+            got = run(g, -1, oracle.ARCTE, monkeypatch, **shape)
+            assert np.array_equal(got[0], ref[0]) and np.array_equal(got[2], ref[2]) and got[3] == ref[3]
+            assert np.array_equal(sorted_rows(got[0], got[1]), sorted_rows(ref[0], ref[1]))
+
+
+@pytest.mark.parametrize("variant", FLAVOURS)
+def test_float32_table_is_invisible_too(variant, monkeypatch):
+    g = load_golden("rmat2000")
+    ref = run(g, 0, variant, monkeypatch, float32=True)
+    for cap in (16, -1):
+        got = run(g, cap, variant, monkeypatch, float32=True)
+        assert np.array_equal(got[0], ref[0]) and np.array_equal(got[2], ref[2]) and got[3] == ref[3]
+        assert np.array_equal(sorted_rows(got[0], got[1]), sorted_rows(ref[0], ref[1]))
+
+
+def test_duplicate_columns_are_rejected():
+    """A column stored twice in a row would make two lanes of one push race: EINVAL at create."""
+    from reveal_graph_embedding_amd import _native
+    indptr = np.array([0, 3, 4, 5], dtype=np.int64)
+    indices = np.array([1, 2, 1, 0, 0], dtype=np.int32)
+    with pytest.raises(_native.ArcteHipError) as e:
+        _native.Context(indptr, indices, np.ones(5), np.ones(3), np.ones(3))
+    assert e.value.code == -1 and "twice" in str(e.value)
