@@ -64,6 +64,42 @@ int arcte_hip_create(int device, int64_t n, int64_t nnz,
 int arcte_hip_destroy(arcte_hip_ctx *ctx);
 
 /*
+ * get_natural_random_walk_matrix (eps_randomwalk/transition.py:43-99) and the seed ordering of arcte()
+ * (embedding/arcte/arcte.py:610-617) ON THE DEVICE, followed by arcte_hip_create's slot set-up: the caller hands
+ * over the ADJACENCY matrix as arcte() holds it after csr_matrix(A) (CSR, any column order inside a row, no
+ * duplicate columns) and never builds W, the degree vectors or the seed list on the host.  Rounding follows scipy:
+ * out_degree = A.sum(axis=1) is data[first] + numpy-pairwise(rest) over the stored row, in_degree = A.sum(axis=0)
+ * a left fold over the column in storage order, zero rows divide by 1 (transition.py:58), columns end up ascending
+ * (transition.py:65).  nnz < 2^31.
+ */
+int arcte_hip_create_from_adjacency(int device, int64_t n, int64_t nnz,
+                                    const int64_t *indptr, const int32_t *indices, const double *data,
+                                    int64_t n_slots, int64_t queue_capacity, arcte_hip_ctx **out);
+
+/*
+ * The same from edge-list triplets (what datautil/datarw.py:54-120 read_adjacency_matrix returns: row, col, value
+ * with ids already renumbered): duplicates are summed like csr_matrix(coo) does (in input order here; scipy's order
+ * for three or more copies of one position is unspecified), and with symmetrise = 1 the matrix becomes
+ * (A + A^T)/2 as in entry_points/arcte.py:70-71 -- all on the device.  nnz < 2^30.
+ */
+int arcte_hip_create_from_coo(int device, int64_t n, int64_t nnz,
+                              const int32_t *row, const int32_t *col, const double *val, int symmetrise,
+                              int64_t n_slots, int64_t queue_capacity, arcte_hip_ctx **out);
+
+/* Sizes of the graph a context holds: nodes, stored transitions, and the length of arcte()'s seed list
+ * (nodes whose pattern in-count exceeds 1, arcte.py:617).  Any pointer may be NULL. */
+int arcte_hip_graph_sizes(arcte_hip_ctx *ctx, int64_t *n, int64_t *nnz, int64_t *nseeds);
+
+/* Copy W (indptr[n+1], indices[nnz], data[nnz]) and the degree vectors to the host: the 3-tuple
+ * get_natural_random_walk_matrix returns (transition.py:99).  Any pointer may be NULL. */
+int arcte_hip_fetch_transition(arcte_hip_ctx *ctx, int64_t *indptr, int32_t *indices, double *data,
+                               double *out_degree, double *in_degree);
+
+/* arcte()'s seed list (arcte.py:610-617): node ids by descending pattern in-count, count > 1 only; ties, which the
+ * reference's unstable argsort leaves unspecified, are in ascending node order.  seeds has nseeds entries. */
+int arcte_hip_fetch_seed_list(arcte_hip_ctx *ctx, int64_t *seeds);
+
+/*
  * calculate_epsilon_effective (embedding/arcte/arcte.py:26-50) for each seed, with the
  * seed's weighted out-degree and its neighbours' out-degrees as at arcte.py:340.
  * The neighbour mean uses numpy's pairwise summation order.
@@ -112,13 +148,15 @@ int arcte_hip_fetch_result(arcte_hip_ctx *ctx, int64_t *colptr, int32_t *rows,
                            double *eps_used, int64_t *nop);
 
 /*
- * The last run as a ROW-compressed matrix, assembled on the device (64-bit key sort): row = node id, column =
- * seed id, columns ascending inside a row -- the CSR that arcte_worker returns (arcte.py:379-388).  With
+ * The last run as a ROW-compressed matrix, assembled on the device (the (member, seed) pairs are laid out in
+ * ascending seed order and stable-sorted by their row id alone: log2(n) key bits, any number of entries): row =
+ * node id, column = seed id, columns ascending inside a row -- the CSR that arcte_worker returns
+ * (arcte.py:379-388).  With
  * with_base_block = 1 the columns are shifted by n and the base-community block I + pattern(W) of
  * arcte.py:676-679 is merged in front, i.e. the result is arcte()'s n x 2n feature pattern (arcte.py:683); a
  * node with a self-loop gets ONE diagonal entry there (the caller stores 2.0 for it, as the reference's I + ones
  * does).  Call arcte_hip_result_csr_size first; indptr has n+1 entries, indices at least that many entries;
- * *nnz_out receives the number of stored entries.  Seeds must be unique for a valid CSR.
+ * *nnz_out receives the number of stored entries.  A run that listed a seed twice is refused (ARCTE_HIP_EINVAL).
  */
 int arcte_hip_result_csr_size(arcte_hip_ctx *ctx, int with_base_block, int64_t *nnz);
 int arcte_hip_fetch_result_csr(arcte_hip_ctx *ctx, int with_base_block, int64_t *indptr, int32_t *indices,
@@ -189,11 +227,58 @@ int arcte_hip_push_variant(int device, int64_t n, double *s, double *r,
 int arcte_hip_set_float32(arcte_hip_ctx *ctx, int enable);
 
 /*
+ * ---- Feature matrices on the device and the weighting the reference applies right after arcte() --------------------
+ * (experiments/utility.py:66 and :101-104).  A features object is a CSR matrix (int64 row pointers, int32 column ids,
+ * float64 values) that lives in HBM; the operations below stream over it in place, so arcte()'s n x 2n result never
+ * has to visit the host between extraction and weighting.
+ */
+typedef struct arcte_hip_features arcte_hip_features;
+
+/* arcte()'s feature matrix of the last run, kept on the device: the pattern of arcte_hip_fetch_result_csr with the
+ * reference's values (1.0; 2.0 on the diagonal of a node with a self-loop, arcte.py:676-679). */
+int arcte_hip_features_from_result(arcte_hip_ctx *ctx, int with_base_block, arcte_hip_features **out);
+/* Any CSR matrix from the host (e.g. a feature matrix made elsewhere). */
+int arcte_hip_features_upload(int device, int64_t n_rows, int64_t n_cols, int64_t nnz,
+                              const int64_t *indptr, const int32_t *indices, const double *data,
+                              arcte_hip_features **out);
+int arcte_hip_features_destroy(arcte_hip_features *f);
+int arcte_hip_features_sizes(arcte_hip_features *f, int64_t *n_rows, int64_t *n_cols, int64_t *nnz);
+/* Copy to the host; any pointer may be NULL. */
+int arcte_hip_features_fetch(arcte_hip_features *f, int64_t *indptr, int32_t *indices, double *data);
+/* features[rows, :] as a new object (the train / test split of experiments/utility.py:94-97). */
+int arcte_hip_features_select_rows(arcte_hip_features *f, const int64_t *rows, int64_t n_selected,
+                                   arcte_hip_features **out);
+
+/* normalize_columns (embedding/common.py:49-67): every column with more than one stored entry is divided by
+ * sqrt(log(number of stored entries)). */
+int arcte_hip_features_normalize_columns(arcte_hip_features *f);
+/* normalize_rows (embedding/common.py:29-46): sklearn normalize(norm="l2"); the squares of a row are summed in storage
+ * order, zero rows stay. */
+int arcte_hip_features_normalize_rows(arcte_hip_features *f);
+/* chi2_contingency_matrix + peak_snr_weight_aggregation (embedding/community_weighting.py:11-84).  Y is the binarised
+ * label matrix in CSR form (y_indptr[n_rows+1], y_indices = class ids of each row), as LabelBinarizer leaves it
+ * (:19-21; the caller expands a binary problem to two classes).  contingency_out (n_classes x n_cols, row-major) may be
+ * NULL; weights_out has n_cols entries. */
+int arcte_hip_features_chi2_psnr_weights(arcte_hip_features *f, const int64_t *y_indptr, const int32_t *y_indices,
+                                         int64_t n_classes, double *contingency_out, double *weights_out);
+/* peak_snr_weight_aggregation (embedding/community_weighting.py:48-84) alone, on a host n_classes x n_cols matrix. */
+int arcte_hip_peak_snr_weights(int device, int64_t n_classes, int64_t n_cols, const double *contingency,
+                               double *weights_out);
+/* community_weighting (embedding/community_weighting.py:87-125) for ONE matrix (the reference runs the same lines on
+ * X_train and X_test): columns with more than one stored entry are multiplied by log(1 + w) (0 when w == 0),
+ * zeros are eliminated, rows are l2-normalised. */
+int arcte_hip_features_community_weighting(arcte_hip_features *f, const double *community_weights);
+
+/*
  * Measurement helper (no counterpart in the reference; SURVEY.md 8(d) asks for the on-box streaming rate beside
  * the 8 TB/s spec figure): the rate of a coalesced 16-byte-per-lane read sweep and of a copy (read + write bytes)
  * over `bytes` of device memory, in GB/s, best of three.
  */
 int arcte_hip_stream_bandwidth(int device, int64_t bytes, double *read_gbps, double *copy_gbps);
+
+/* Diagnostic: how many workgroups of the float64 ARCTE propagation kernel the runtime's occupancy query admits per
+ * compute unit with the context's launch shape (the slot count assumes info[7] / info[4] of them). */
+int arcte_hip_launch_occupancy(arcte_hip_ctx *ctx, int *workgroups_per_cu);
 
 /* Properties of the context: info[0] slots, [1] queue capacity, [2] device bytes held,
  * [3] compute units, [4] wavefronts per workgroup of the propagation kernel, [5] values of the LDS-resident hot

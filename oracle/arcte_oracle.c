@@ -485,6 +485,87 @@ int64_t oracle_push_trace(int64_t n, const int64_t *indptr, const int32_t *indic
     return len;
 }
 
+
+/* ------------------------------------------------------------------------ */
+/* embedding/arcte/cython_opt/arcte.pyx:125-241  arcte_and_centrality         */
+/* ------------------------------------------------------------------------ */
+/*
+ * The OTHER driver of the reference (single process, never called by its pipeline): every node with out-edges is a
+ * seed, in index order (arcte.pyx:165-166); the propagation runs with the RAW epsilon (:172-180); the degree-
+ * normalised slice is ADDED to a centrality vector seed after seed (:190-191: per node a left fold in seed order);
+ * the community is found by scanning the sorted support from the top until every member of the closed
+ * neighbourhood has been seen (:194-208) and emitted iff that takes more entries than the neighbourhood has
+ * (:211-215, a set: a self-loop does not count twice); emitted communities get consecutive column numbers.
+ * Where a node OUTSIDE the closed neighbourhood ties with the smallest value inside it, the scan's result depends
+ * on the order numpy's unstable argsort leaves ties in; this restatement takes every node at or above that value
+ * (one of the legal outcomes, and THE outcome whenever no such tie exists -- the fixtures mark tied seeds).
+ * Nodes without out-edges keep centrality 1.0 (arcte.pyx:210; the reference itself raises there once any seed
+ * has run, because its centrality has silently become a 1 x n matrix).
+ *
+ * colptr[n+1] / *rows_out: community of seed i = rows[colptr[i] .. colptr[i+1]) (ascending ids; empty when nothing
+ * is emitted).  centrality[n] is overwritten.  Returns 0, -1 on allocation failure.
+ */
+int oracle_arcte_and_centrality(int64_t n, const int64_t *indptr, const int32_t *indices, const double *data,
+                                const double *in_degree, double rho, double epsilon, int64_t *colptr,
+                                int32_t **rows_out, double *centrality)
+{
+    double *s = (double *)calloc((size_t)n, sizeof(double));
+    double *r = (double *)calloc((size_t)n, sizeof(double));
+    int32_t *touched = (int32_t *)malloc((size_t)(n > 0 ? n : 1) * sizeof(int32_t));
+    ivec_t out = {0, 0, 0};
+    fifo_t q = {0, 0, 0, 0};
+    int rc = 0;
+    if (!s || !r || !touched) rc = -1;
+    for (int64_t i = 0; i < n; i++) centrality[i] = 0.0;
+    colptr[0] = 0;
+    for (int64_t seed = 0; seed < n && !rc; seed++) {
+        colptr[seed + 1] = colptr[seed];
+        const int64_t b = indptr[seed], e = indptr[seed + 1];
+        if (e == b) continue;                                   /* arcte.pyx:165: out_degree != 0 */
+        int64_t ntouched = 0;
+        int64_t nop = similarity_core_v(0, 0.0, indptr, indices, data, in_degree, seed, rho, epsilon, s, r, &q, touched,
+                                        &ntouched, 0, 0, 0);
+        if (nop < 0) { rc = -1; break; }
+        /* arcte.pyx:183-191: degree normalisation and the centrality update (ascending node order inside a seed is
+         * irrelevant: every node receives exactly one addend per seed) */
+        qsort(touched, (size_t)ntouched, sizeof(int32_t), cmp_i32);
+        for (int64_t t = 0; t < ntouched; t++) {
+            const int32_t v = touched[t];
+            centrality[v] += s[v] / in_degree[v];
+        }
+        /* arcte.pyx:199-215 */
+        int self_loop = 0, missing = (s[seed] == 0.0);
+        double thr = s[seed] / in_degree[seed];
+        for (int64_t k = b; k < e; k++) {
+            const int32_t v = indices[k];
+            if (v == seed) self_loop = 1;
+            if (s[v] == 0.0) missing = 1;
+            const double x = s[v] / in_degree[v];
+            if (x < thr) thr = x;
+        }
+        const int64_t base_size = (e - b) + (self_loop ? 0 : 1);
+        if (!missing) {
+            int64_t cnt = 0;
+            for (int64_t t = 0; t < ntouched; t++)
+                if (s[touched[t]] / in_degree[touched[t]] >= thr) cnt++;
+            if (cnt > base_size) {
+                if (ivec_reserve(&out, cnt)) { rc = -1; break; }
+                for (int64_t t = 0; t < ntouched; t++)
+                    if (s[touched[t]] / in_degree[touched[t]] >= thr) out.buf[out.len++] = touched[t];
+                colptr[seed + 1] = colptr[seed] + cnt;
+            }
+        }
+        /* back to zero: s is non-zero exactly on the touched list; r only where s is (every deposit adds to both) */
+        for (int64_t t = 0; t < ntouched; t++) { s[touched[t]] = 0.0; r[touched[t]] = 0.0; }
+    }
+    for (int64_t i = 0; i < n && !rc; i++)
+        if (indptr[i + 1] == indptr[i]) centrality[i] = 1.0;    /* arcte.pyx:210 */
+    free(s); free(r); free(touched); free(q.buf);
+    if (rc) { free(out.buf); *rows_out = 0; return rc; }
+    *rows_out = out.buf ? out.buf : (int32_t *)malloc(sizeof(int32_t));
+    return 0;
+}
+
 void oracle_free(void *p) { free(p); }
 
 int oracle_max_threads(void)

@@ -61,6 +61,9 @@ def lib():
         l.oracle_similarity_variant.argtypes = [C.c_int, C.c_double] + l.oracle_similarity.argtypes
         l.oracle_push_variant.restype = None
         l.oracle_push_variant.argtypes = [C.c_int, C.c_double] + l.oracle_push.argtypes
+        l.oracle_arcte_and_centrality.restype = C.c_int
+        l.oracle_arcte_and_centrality.argtypes = [C.c_int64, _i64p, _i32p, _f64p, _f64p, C.c_double, C.c_double, _i64p,
+                                                  C.POINTER(C.POINTER(C.c_int32)), _f64p]
         l.oracle_free.restype = None
         l.oracle_free.argtypes = [C.c_void_p]
         l.oracle_max_threads.restype = C.c_int
@@ -205,3 +208,121 @@ def arcte(adjacency_matrix, rho, epsilon, number_of_threads=1, variant=0):
     ones.data = np.ones_like(ones.data)                                             # :677-678
     base = identity + ones                                                          # :679
     return sparse.hstack([base, local]).tocsr()                                     # :683
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# embedding/arcte/cython_opt/arcte.pyx:125-241 and the feature weighting behind it (embedding/common.py,
+# embedding/community_weighting.py)
+# ---------------------------------------------------------------------------------------------------------------------
+
+def normalize_columns(features):
+    """common.py:49-67: every column with more than one stored entry is divided by sqrt(log(stored entries))."""
+    f = sparse.csc_matrix(features, dtype=np.float64, copy=True)
+    df = np.diff(f.indptr)
+    scale = np.ones(f.shape[1])
+    big = df > 1
+    scale[big] = np.sqrt(np.log(df[big]))
+    f.data = f.data / np.repeat(scale, df)
+    return f.tocsr()
+
+
+def normalize_rows(features):
+    """common.py:29-46: sklearn normalize(norm="l2") = every row divided by sqrt(sum of squares) (zero rows stay),
+    the squares summed in storage order (sklearn/utils/sparsefuncs_fast.pyx inplace_csr_row_normalize_l2)."""
+    f = sparse.csr_matrix(features, dtype=np.float64, copy=True)
+    for i in range(f.shape[0]):
+        lo, hi = f.indptr[i], f.indptr[i + 1]
+        acc = 0.0
+        for x in f.data[lo:hi]:
+            acc += x * x
+        if acc != 0.0:
+            f.data[lo:hi] /= np.sqrt(acc)
+    return f
+
+
+def normalize_community_features(features):
+    """common.py:8-26"""
+    return normalize_rows(normalize_columns(features))
+
+
+def arcte_and_centrality(adjacency_matrix, rho, epsilon):
+    """arcte.pyx:125-241.  Returns (features n x (n + emitted communities) CSR, centrality[n])."""
+    a = sparse.csr_matrix(adjacency_matrix, dtype=np.float64)
+    n = a.shape[0]
+    w, out_degree, in_degree = get_natural_random_walk_matrix(a)
+    indptr, indices, data = _csr_arrays(w)
+    colptr = np.zeros(n + 1, dtype=np.int64)
+    rows_p = C.POINTER(C.c_int32)()
+    centrality = np.zeros(n, dtype=np.float64)
+    rc = lib().oracle_arcte_and_centrality(n, indptr, indices, data, np.ascontiguousarray(in_degree, dtype=np.float64),
+                                           float(rho), float(epsilon), colptr, C.byref(rows_p), centrality)
+    if rc != 0:
+        raise RuntimeError("oracle_arcte_and_centrality failed with status %d" % rc)
+    total = int(colptr[-1])
+    rows = np.ctypeslib.as_array(rows_p, shape=(max(total, 1),))[:total].copy()
+    lib().oracle_free(rows_p)
+    sizes = np.diff(colptr)
+    emitted = np.flatnonzero(sizes)
+    cols = np.repeat(np.arange(emitted.size), sizes[emitted])                      # arcte.pyx:213-215: running counter
+    local = sparse.coo_matrix((np.ones(rows.size), (rows.astype(np.int64), cols)), shape=(n, emitted.size))
+    # arcte.pyx:227-228 says identity + adjacency_matrix, but by then the reference's adjacency_matrix IS the
+    # transition matrix: cython_opt/transition.pyx:19 wraps its float64 CSR argument without copy=True and
+    # normalises the rows in place, so the base block carries the weights of W (row sums 1), not of A
+    base = sparse.csr_matrix(sparse.eye(n, n, dtype=np.float64)) + w
+    features = sparse.hstack([base, local]).tocoo() if emitted.size else base      # :231-234
+    return normalize_community_features(features), centrality
+
+
+def chi2_contingency_matrix(x_train, y_train):
+    """community_weighting.py:11-45 (LabelBinarizer = one column per sorted class; two classes get both columns)."""
+    x = sparse.csr_matrix(x_train, dtype=np.float64, copy=True)
+    x.data = np.ones_like(x.data)
+    classes = np.unique(y_train)
+    y = (np.asarray(y_train).reshape(-1, 1) == classes.reshape(1, -1)).astype(np.int64)
+    if y.shape[1] == 1:                     # a single class: LabelBinarizer gives one all-zero column
+        y = np.zeros((y.shape[0], 1), dtype=np.int64)
+        y = np.append(1 - y, y, axis=1)
+    elif y.shape[1] == 2:                   # binary: LabelBinarizer gives the second class only, then [1 - y, y]
+        y = y[:, 1:2]
+        y = np.append(1 - y, y, axis=1)
+    observed = np.asarray((x.T @ y).T, dtype=np.float64)
+    feature_count = np.asarray(x.sum(axis=0)).reshape(1, -1)
+    class_prob = y.mean(axis=0).reshape(1, -1)
+    expected = np.dot(class_prob.T, feature_count)
+    m = observed
+    m -= expected
+    m **= 2
+    expected[expected == 0.0] = 1.0
+    m /= expected
+    return m
+
+
+def peak_snr_weight_aggregation(contingency_matrix):
+    """community_weighting.py:48-84"""
+    c = np.array(contingency_matrix, dtype=np.float64)
+    c[np.isnan(c)] = 0.0
+    variance = np.sqrt(np.mean([np.var(c[k, :]) for k in range(c.shape[0])]))
+    weights = np.zeros(c.shape[1])
+    for f in range(c.shape[1]):
+        d = c[:, f]
+        d = d[d > 0.0]
+        if d.size > 1:
+            weights[f] = (np.max(d) - np.min(d)) / variance
+        elif d.size == 1:
+            weights[f] = np.max(d) / variance
+    return weights
+
+
+def community_weighting(x_train, x_test, community_weights):
+    """community_weighting.py:87-125"""
+    out = []
+    for x in (x_train, x_test):
+        f = sparse.csc_matrix(x, dtype=np.float64, copy=True)
+        df = np.diff(f.indptr)
+        reinforcement = np.where(np.asarray(community_weights) == 0.0, 0.0, np.log(1.0 + np.asarray(community_weights, dtype=np.float64)))
+        scale = np.where(df > 1, reinforcement, 1.0)
+        f.data = f.data * np.repeat(scale, df)
+        f = f.tocsr()
+        f.eliminate_zeros()
+        out.append(normalize_rows(f))
+    return out[0], out[1]

@@ -24,6 +24,13 @@ SIGNATURES = {
     "arcte_hip_create": (C.c_int, [C.c_int, C.c_int64, C.c_int64, _i64p, _i32p, _f64p, _f64p, _f64p,
                                    C.c_int64, C.c_int64, C.POINTER(C.c_void_p)]),
     "arcte_hip_destroy": (C.c_int, [C.c_void_p]),
+    "arcte_hip_create_from_adjacency": (C.c_int, [C.c_int, C.c_int64, C.c_int64, _i64p, _i32p, _f64p, C.c_int64, C.c_int64,
+                                                  C.POINTER(C.c_void_p)]),
+    "arcte_hip_create_from_coo": (C.c_int, [C.c_int, C.c_int64, C.c_int64, _i32p, _i32p, _f64p, C.c_int, C.c_int64, C.c_int64,
+                                            C.POINTER(C.c_void_p)]),
+    "arcte_hip_graph_sizes": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "arcte_hip_fetch_transition": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "arcte_hip_fetch_seed_list": (C.c_int, [C.c_void_p, C.c_void_p]),
     "arcte_hip_epsilon_effective": (C.c_int, [C.c_void_p, _i64p, C.c_int64, C.c_double, _f64p]),
     "arcte_hip_run_seeds": (C.c_int, [C.c_void_p, _i64p, C.c_int64, C.c_double, C.c_double, C.c_int]),
     "arcte_hip_run_seeds_variant": (C.c_int, [C.c_void_p, _i64p, C.c_int64, C.c_double, C.c_double, C.c_int, C.c_int,
@@ -47,6 +54,18 @@ SIGNATURES = {
     "arcte_hip_set_float32": (C.c_int, [C.c_void_p, C.c_int]),
     "arcte_hip_stream_bandwidth": (C.c_int, [C.c_int, C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "arcte_hip_info": (C.c_int, [C.c_void_p, _i64p]),
+    "arcte_hip_launch_occupancy": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
+    "arcte_hip_features_from_result": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
+    "arcte_hip_features_upload": (C.c_int, [C.c_int, C.c_int64, C.c_int64, C.c_int64, _i64p, _i32p, _f64p, C.POINTER(C.c_void_p)]),
+    "arcte_hip_features_destroy": (C.c_int, [C.c_void_p]),
+    "arcte_hip_features_sizes": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "arcte_hip_features_fetch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "arcte_hip_features_select_rows": (C.c_int, [C.c_void_p, _i64p, C.c_int64, C.POINTER(C.c_void_p)]),
+    "arcte_hip_features_normalize_columns": (C.c_int, [C.c_void_p]),
+    "arcte_hip_features_normalize_rows": (C.c_int, [C.c_void_p]),
+    "arcte_hip_features_chi2_psnr_weights": (C.c_int, [C.c_void_p, _i64p, _i32p, C.c_int64, C.c_void_p, _f64p]),
+    "arcte_hip_features_community_weighting": (C.c_int, [C.c_void_p, _f64p]),
+    "arcte_hip_peak_snr_weights": (C.c_int, [C.c_int, C.c_int64, C.c_int64, _f64p, _f64p]),
 }
 
 # push flavours (include/arcte_hip.h: `variant`)
@@ -117,6 +136,65 @@ class Context:
                                       out_degree, in_degree, int(n_slots), int(queue_capacity), C.byref(h)))
         self._h = h
         self.device = int(device)
+
+    @classmethod
+    def _adopt(cls, handle, device):
+        self = cls.__new__(cls)
+        self._h = handle
+        self.device = int(device)
+        self.n = self.graph_sizes()[0]
+        return self
+
+    @classmethod
+    def from_adjacency(cls, indptr, indices, data, device=0, n_slots=0, queue_capacity=0):
+        """Context from the ADJACENCY matrix (CSR): W, the degree vectors and the seed list are made on the device."""
+        indptr = np.ascontiguousarray(indptr, dtype=np.int64)
+        indices = np.ascontiguousarray(indices, dtype=np.int32)
+        data = np.ascontiguousarray(data, dtype=np.float64)
+        if indices.size != data.size or indptr.size < 2:
+            raise ValueError("inconsistent CSR array sizes")
+        h = C.c_void_p()
+        _check(lib().arcte_hip_create_from_adjacency(int(device), int(indptr.size - 1), int(indices.size), indptr, indices, data,
+                                                     int(n_slots), int(queue_capacity), C.byref(h)))
+        return cls._adopt(h, device)
+
+    @classmethod
+    def from_coo(cls, n, row, col, val, symmetrise=False, device=0, n_slots=0, queue_capacity=0):
+        """Context from edge-list triplets; symmetrise=True makes (A + A^T)/2 first (entry_points/arcte.py:70-71)."""
+        row = np.ascontiguousarray(row, dtype=np.int32)
+        col = np.ascontiguousarray(col, dtype=np.int32)
+        val = np.ascontiguousarray(val, dtype=np.float64)
+        if not (row.size == col.size == val.size):
+            raise ValueError("row, col and val must have one entry per triplet")
+        h = C.c_void_p()
+        _check(lib().arcte_hip_create_from_coo(int(device), int(n), int(row.size), row, col, val, 1 if symmetrise else 0,
+                                               int(n_slots), int(queue_capacity), C.byref(h)))
+        return cls._adopt(h, device)
+
+    def graph_sizes(self):
+        """(nodes, stored transitions, length of arcte()'s seed list)."""
+        n, nnz, ns = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        _check(lib().arcte_hip_graph_sizes(self._h, C.byref(n), C.byref(nnz), C.byref(ns)))
+        return n.value, nnz.value, ns.value
+
+    def transition(self):
+        """(indptr, indices, data, out_degree, in_degree) of W as held on the device."""
+        n, nnz, _ = self.graph_sizes()
+        indptr = np.zeros(n + 1, dtype=np.int64)
+        indices = np.zeros(nnz, dtype=np.int32)
+        data = np.zeros(nnz, dtype=np.float64)
+        od = np.zeros(n, dtype=np.float64)
+        idg = np.zeros(n, dtype=np.float64)
+        _check(lib().arcte_hip_fetch_transition(self._h, indptr.ctypes.data, indices.ctypes.data if nnz else None,
+                                                data.ctypes.data if nnz else None, od.ctypes.data, idg.ctypes.data))
+        return indptr, indices, data, od, idg
+
+    def seed_list(self):
+        """arcte()'s seed list (arcte.py:610-617), made on the device."""
+        ns = self.graph_sizes()[2]
+        seeds = np.zeros(ns, dtype=np.int64)
+        _check(lib().arcte_hip_fetch_seed_list(self._h, seeds.ctypes.data if ns else None))
+        return seeds
 
     def close(self):
         if self._h is not None:
@@ -217,6 +295,12 @@ class Context:
                     waves_per_workgroup=int(i[4]), hot_values_per_wave=int(i[5]), tiles=int(i[6]),
                     waves_per_cu=int(i[7]))
 
+    def launch_occupancy(self):
+        """Workgroups of the propagation kernel per CU according to the runtime's occupancy query (diagnostic)."""
+        k = C.c_int(0)
+        _check(lib().arcte_hip_launch_occupancy(self._h, C.byref(k)))
+        return k.value
+
     def similarity_slice(self, seed, rho, epsilon, s, r, variant=ARCTE, laziness_factor=0.5):
         if s.dtype != np.float64 or r.dtype != np.float64 or not s.flags.c_contiguous or not r.flags.c_contiguous:
             raise TypeError("s and r must be C-contiguous float64 arrays (they are updated in place)")
@@ -226,6 +310,106 @@ class Context:
         _check(lib().arcte_hip_similarity_slice_variant(self._h, int(seed), float(rho), float(epsilon), int(variant),
                                                         float(laziness_factor), s, r, C.byref(nop)))
         return nop.value
+
+
+class Features:
+    """A CSR feature matrix resident on one GPU (include/arcte_hip.h: arcte_hip_features)."""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    @classmethod
+    def from_result(cls, ctx, with_base_block=True):
+        h = C.c_void_p()
+        _check(lib().arcte_hip_features_from_result(ctx._h, 1 if with_base_block else 0, C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def upload(cls, matrix, device=0):
+        """From a scipy sparse matrix (converted to CSR float64)."""
+        import scipy.sparse as sparse
+        m = sparse.csr_matrix(matrix, dtype=np.float64)
+        indptr = np.ascontiguousarray(m.indptr, dtype=np.int64)
+        indices = np.ascontiguousarray(m.indices, dtype=np.int32)
+        data = np.ascontiguousarray(m.data, dtype=np.float64)
+        h = C.c_void_p()
+        _check(lib().arcte_hip_features_upload(int(device), m.shape[0], m.shape[1], int(indices.size), indptr, indices, data,
+                                               C.byref(h)))
+        return cls(h)
+
+    def close(self):
+        if self._h is not None:
+            lib().arcte_hip_features_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def sizes(self):
+        r, c, z = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        _check(lib().arcte_hip_features_sizes(self._h, C.byref(r), C.byref(c), C.byref(z)))
+        return r.value, c.value, z.value
+
+    def to_scipy(self):
+        import scipy.sparse as sparse
+        rows, cols, nnz = self.sizes()
+        indptr = np.zeros(rows + 1, dtype=np.int64)
+        indices = np.zeros(nnz, dtype=np.int32)
+        data = np.zeros(nnz, dtype=np.float64)
+        _check(lib().arcte_hip_features_fetch(self._h, indptr.ctypes.data, indices.ctypes.data if nnz else None,
+                                              data.ctypes.data if nnz else None))
+        index_dtype = np.int32 if max(cols, nnz) < 2 ** 31 else np.int64
+        return sparse.csr_matrix((data, indices.astype(index_dtype, copy=False), indptr.astype(index_dtype)), shape=(rows, cols))
+
+    def select_rows(self, rows):
+        rows = np.ascontiguousarray(rows, dtype=np.int64)
+        h = C.c_void_p()
+        _check(lib().arcte_hip_features_select_rows(self._h, rows, rows.size, C.byref(h)))
+        return Features(h)
+
+    def normalize_columns(self):
+        _check(lib().arcte_hip_features_normalize_columns(self._h))
+        return self
+
+    def normalize_rows(self):
+        _check(lib().arcte_hip_features_normalize_rows(self._h))
+        return self
+
+    def chi2_psnr_weights(self, y_indptr, y_indices, n_classes, want_contingency=False):
+        y_indptr = np.ascontiguousarray(y_indptr, dtype=np.int64)
+        y_indices = np.ascontiguousarray(y_indices, dtype=np.int32)
+        _, cols, _ = self.sizes()
+        weights = np.zeros(cols, dtype=np.float64)
+        cont = np.zeros((int(n_classes), cols), dtype=np.float64) if want_contingency else None
+        _check(lib().arcte_hip_features_chi2_psnr_weights(self._h, y_indptr, y_indices, int(n_classes),
+                                                          cont.ctypes.data if want_contingency else None, weights))
+        return (cont, weights) if want_contingency else weights
+
+    def community_weighting(self, community_weights):
+        w = np.ascontiguousarray(community_weights, dtype=np.float64)
+        if w.size != self.sizes()[1]:
+            raise ValueError("one weight per column")
+        _check(lib().arcte_hip_features_community_weighting(self._h, w))
+        return self
+
+
+def peak_snr_weights(contingency_matrix, device=0):
+    """peak_snr_weight_aggregation (community_weighting.py:48-84) of a host classes x communities matrix."""
+    m = np.ascontiguousarray(contingency_matrix, dtype=np.float64)
+    if m.ndim != 2:
+        raise ValueError("the contingency matrix is classes x communities")
+    out = np.zeros(m.shape[1], dtype=np.float64)
+    _check(lib().arcte_hip_peak_snr_weights(int(device), m.shape[0], m.shape[1], m, out))
+    return out
 
 
 def single_push(s, r, w_i, a_i, push_node, rho, device=0, variant=ARCTE, laziness_factor=0.5):

@@ -31,6 +31,8 @@
 #include "arcte_hip.h"
 
 #include "arcte_kernels.hpp"
+#include "arcte_prepare.hpp"
+#include "arcte_features.hpp"
 
 namespace {
 
@@ -145,6 +147,8 @@ struct arcte_hip_ctx {
     // hot table (LDS-resident state of the highest-degree nodes) and the launch shape that goes with it
     DevBuf<uint16_t> node_hot, edge_hot;
     int64_t hot_ranked = 0;      // nodes that carry a rank (<= HOT_NONE)
+    DevBuf<int32_t> ranked_ids;  // every node by descending pattern in-count, ties by node id (stable)
+    int64_t nseeds_all = 0;      // arcte.py:617: how many of them have an in-count above 1 = the seed list
     int waves_per_block = 1;     // wavefronts per workgroup of k_arcte_seeds
     int waves_per_cu = 0;        // resident wavefronts per CU the slot count was sized for
     int tiles = 2;               // 64-edge tiles per push iteration
@@ -249,7 +253,11 @@ uint32_t hot_values_per_wave(const arcte_hip_ctx *c, size_t value_bytes)
 {
     const int cap = env_int("ARCTE_HIP_HOT", -1);
     if (cap == 0 || c->hot_ranked <= 0 || c->waves_per_cu <= 0) return 0;
-    size_t per_wave = LDS_PER_CU / (size_t)c->waves_per_cu;
+    // A share that fills the LDS to the last byte does not reliably leave room for the intended number of
+    // workgroups per CU (launch-shape sweeps: 3 x 52 KiB, 5 x 32 KiB, 6 x 26 KiB and, on some boxes, 4 x 40 KiB ran
+    // like one workgroup fewer); 8 KiB are left unclaimed.
+    const size_t reserve = (size_t)std::max(0, env_int("ARCTE_HIP_LDS_RESERVE_KB", 8)) * 1024;
+    size_t per_wave = (LDS_PER_CU - std::min(reserve, LDS_PER_CU / 2)) / (size_t)c->waves_per_cu;
     per_wave = per_wave / 1024 * 1024;
     uint64_t k = per_wave / value_bytes;
     k = std::min<uint64_t>(k, (uint64_t)c->hot_ranked);
@@ -327,6 +335,215 @@ int launch_seeds(arcte_hip_ctx *c, const PushParams &P, int64_t nwork, int varia
     return launch_seeds_t<MODE, double>(c, P, nwork, variant);
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// context construction: begin (device, stream, graph buffers) -> graph arrays on the device -> finish
+// ---------------------------------------------------------------------------------------------
+int ctx_begin(int device, int64_t n, int64_t nnz, arcte_hip_ctx **out)
+{
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail(ARCTE_HIP_EHIP, "no such HIP device");
+    HIP_TRY(hipSetDevice(device));
+    arcte_hip_ctx *c = new arcte_hip_ctx();
+    c->device = device;
+    c->n = n;
+    c->nnz = nnz;
+    int rc = [&]() -> int {
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, device));
+        c->cus = prop.multiProcessorCount;
+        HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        for (auto &e : c->ev) HIP_TRY(hipEventCreate(&e));
+        HIP_TRY(c->indptr.alloc(n + 1));
+        HIP_TRY(c->indices.alloc(nnz));
+        HIP_TRY(c->data.alloc(nnz));
+        HIP_TRY(c->out_degree.alloc(n));
+        HIP_TRY(c->in_degree.alloc(n));
+        HIP_TRY(c->counters.alloc(8));
+        return 0;
+    }();
+    if (rc) {
+        std::string keep = g_err;
+        arcte_hip_destroy(c);
+        g_err = keep;
+        return rc;
+    }
+    *out = c;
+    return 0;
+}
+
+// Pattern in-count of every node and the nodes in descending-count order (stable: ties keep the node order).
+// Serves the seed list of arcte() (arcte.py:610-617) and the ranks of the hot table.
+int rank_nodes(arcte_hip_ctx *c, DevBuf<uint32_t> &count)
+{
+    const int64_t n = c->n, nnz = c->nnz;
+    DevBuf<uint32_t> keys_in, keys_out;
+    DevBuf<int32_t> ids_in;
+    DevBuf<char> temp;
+    int rk = [&]() -> int {
+        HIP_TRY(count.alloc(n));
+        HIP_TRY(keys_in.alloc(n));
+        HIP_TRY(keys_out.alloc(n));
+        HIP_TRY(ids_in.alloc(n));
+        HIP_TRY(c->ranked_ids.alloc(n));
+        HIP_TRY(hipMemsetAsync(count.p, 0, count.bytes(), c->stream));
+        HIP_TRY(hipMemsetAsync(c->counters.p, 0, 8 * sizeof(unsigned long long), c->stream));
+        const int tb = 256;
+        if (nnz) hipLaunchKernelGGL(k_column_counts, dim3((unsigned)((nnz + tb - 1) / tb)), dim3(tb), 0, c->stream, c->indices.p, nnz, count.p);
+        hipLaunchKernelGGL(k_rank_keys, dim3((unsigned)((n + tb - 1) / tb)), dim3(tb), 0, c->stream, count.p, n, keys_in.p, ids_in.p);
+        hipLaunchKernelGGL(k_count_seeds, dim3((unsigned)((n + tb - 1) / tb)), dim3(tb), 0, c->stream, count.p, n, c->counters.p);
+        HIP_TRY(hipGetLastError());
+        size_t temp_bytes = 0;
+        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, keys_in.p, keys_out.p, ids_in.p, c->ranked_ids.p, (int)n, 0, 32, c->stream));
+        HIP_TRY(temp.alloc(temp_bytes));
+        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(temp.p, temp_bytes, keys_in.p, keys_out.p, ids_in.p, c->ranked_ids.p, (int)n, 0, 32, c->stream));
+        unsigned long long ns = 0;
+        HIP_TRY(hipMemcpyAsync(&ns, c->counters.p, sizeof(ns), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        c->nseeds_all = (int64_t)ns;
+        return 0;
+    }();
+    keys_in.release(); keys_out.release(); ids_in.release(); temp.release();
+    return rk;
+}
+
+// Everything after the transition matrix and the degree vectors are on the device (indptr, indices, data,
+// out_degree, in_degree): per-edge in_degree, node ranking, hot-table ranks, launch shape, slots.
+int ctx_finish(arcte_hip_ctx *c, int64_t n_slots, int64_t queue_capacity)
+{
+    const int64_t n = c->n, nnz = c->nnz;
+    if (c->row_len.size() != (size_t)n) {
+        std::vector<int64_t> ip((size_t)n + 1);
+        HIP_TRY(hipMemcpyAsync(ip.data(), c->indptr.p, (n + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        c->row_len.resize((size_t)n);
+        for (int64_t i = 0; i < n; i++) c->row_len[i] = (int32_t)std::min<int64_t>(ip[i + 1] - ip[i], INT32_MAX);
+    }
+    HIP_TRY(c->edge_in_degree.alloc(nnz));
+    if (nnz) {
+        hipLaunchKernelGGL(k_edge_in_degree, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, c->stream, c->indices.p,
+                           c->in_degree.p, c->edge_in_degree.p, nnz);
+        HIP_TRY(hipGetLastError());
+    }
+    // ---- hot table: the ranks stream with the rows.  All on the device; the host never sees the ranking.
+    {
+        const int64_t ranked = std::min<int64_t>(n, (int64_t)HOT_NONE);
+        HIP_TRY(c->node_hot.alloc(n));
+        HIP_TRY(c->edge_hot.alloc(nnz));
+        HIP_TRY(hipMemsetAsync(c->node_hot.p, 0xFF, c->node_hot.bytes(), c->stream));
+        DevBuf<uint32_t> cnt;
+        int rk = rank_nodes(c, cnt);
+        cnt.release();
+        if (rk) return rk;
+        const int tb = 256;
+        hipLaunchKernelGGL(k_assign_hot, dim3((unsigned)((ranked + tb - 1) / tb)), dim3(tb), 0, c->stream, c->ranked_ids.p, ranked, c->node_hot.p);
+        if (nnz) hipLaunchKernelGGL(k_edge_hot, dim3((unsigned)((nnz + tb - 1) / tb)), dim3(tb), 0, c->stream, c->indices.p, c->node_hot.p, c->edge_hot.p, nnz);
+        HIP_TRY(hipGetLastError());
+        c->hot_ranked = ranked;
+    }
+    // ---- launch shape.  The propagation kernel is bound by the chip's random-access rate into the per-slot HBM
+    //      state, and the LDS-resident hot table takes 20-40 % of those accesses away -- the more the fewer
+    //      wavefronts share a CU's LDS, while fewer wavefronts keep fewer accesses in flight.
+    c->waves_per_block = std::max(1, std::min(env_int("ARCTE_HIP_WAVES_PER_BLOCK", 1), WAVES_PER_BLOCK));
+    c->tiles = env_int("ARCTE_HIP_TILES", 2) == 4 ? 4 : 2;
+    const int wpb = c->waves_per_block;
+    int64_t slots = n_slots;
+    if (slots <= 0) {
+        c->waves_per_cu = std::max(1, std::min(env_int("ARCTE_HIP_WAVES_PER_CU", 4), 32));
+        slots = (int64_t)c->waves_per_cu * c->cus;
+        // keep the slot scratch within a fixed share of the device
+        size_t free_b = 0, total_b = 0;
+        HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+        size_t per_slot = (size_t)n * (sizeof(Entry) + sizeof(int32_t)) + (size_t)default_queue_capacity(n) * sizeof(QEntry);
+        while (slots > c->cus && (size_t)slots * per_slot > free_b / 4 * 3) slots -= c->cus / 2;
+    }
+    slots = std::max<int64_t>(wpb, (slots + wpb - 1) / wpb * wpb);
+    c->waves_per_cu = (int)std::max<int64_t>(1, std::min<int64_t>(32, (slots + c->cus - 1) / c->cus));
+    uint32_t qcap = queue_capacity > 0 ? next_pow2((uint64_t)queue_capacity) : default_queue_capacity(n);
+    if (qcap < (uint32_t)WAVE) qcap = WAVE;
+    int r = alloc_slots(c, slots, qcap);
+    if (r) return r;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// get_natural_random_walk_matrix (transition.py:43-99) on the device.  On entry c->indptr / indices / data hold the
+// ADJACENCY matrix as stored (any column order inside a row); on exit they hold W = D_out^-1 A with ascending
+// columns, and out_degree / in_degree the weighted degrees, rounded as scipy rounds them (arcte_prepare.hpp).
+int transition_on_device(arcte_hip_ctx *c)
+{
+    const int64_t n = c->n, nnz = c->nnz;
+    const int tb = 256;
+    const int row_blocks = (int)((n + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
+    DevBuf<int32_t> flags, idx_sorted;
+    DevBuf<uint32_t> count;
+    DevBuf<int64_t> colptr;
+    DevBuf<double> vals_by_col;
+    DevBuf<uint64_t> keys_in, keys_out;
+    DevBuf<double> data_sorted;
+    DevBuf<char> temp;
+    int rc = [&]() -> int {
+        int32_t fl[2] = {0, 0};
+        HIP_TRY(flags.alloc(2));
+        HIP_TRY(hipMemsetAsync(flags.p, 0, 2 * sizeof(int32_t), c->stream));
+        hipLaunchKernelGGL(k_check_rows, dim3(row_blocks), dim3(BLOCK), 0, c->stream, c->indptr.p, c->indices.p, n, flags.p);
+        HIP_TRY(hipMemcpyAsync(fl, flags.p, sizeof(fl), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (fl[0]) return fail(ARCTE_HIP_EINVAL, "column index out of range");
+        // transition.py:55-58 (sums are taken in STORAGE order, before sort_indices)
+        hipLaunchKernelGGL(k_out_degree, dim3(row_blocks), dim3(BLOCK), 0, c->stream, c->indptr.p, c->data.p, n, c->out_degree.p);
+        // transition.py:56: stable sort of the stored entries by column, then one left fold per column
+        HIP_TRY(count.alloc(n));
+        HIP_TRY(colptr.alloc(n + 1));
+        HIP_TRY(vals_by_col.alloc(nnz));
+        HIP_TRY(idx_sorted.alloc(nnz));
+        HIP_TRY(hipMemsetAsync(count.p, 0, count.bytes(), c->stream));
+        HIP_TRY(hipMemsetAsync(colptr.p, 0, sizeof(int64_t), c->stream));
+        if (nnz) hipLaunchKernelGGL(k_column_counts, dim3((unsigned)((nnz + tb - 1) / tb)), dim3(tb), 0, c->stream, c->indices.p, nnz, count.p);
+        hipLaunchKernelGGL(k_u32_to_i64, dim3((unsigned)((n + tb - 1) / tb)), dim3(tb), 0, c->stream, count.p, n, colptr.p + 1);
+        HIP_TRY(hipGetLastError());
+        size_t tb1 = 0, tb2 = 0;
+        HIP_TRY(hipcub::DeviceScan::InclusiveSum(nullptr, tb1, colptr.p + 1, colptr.p + 1, (int)n, c->stream));
+        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tb2, reinterpret_cast<const uint32_t *>(c->indices.p),
+                                                   reinterpret_cast<uint32_t *>(idx_sorted.p), c->data.p, vals_by_col.p, (int)nnz, 0, 32, c->stream));
+        HIP_TRY(temp.alloc(std::max(tb1, tb2)));
+        HIP_TRY(hipcub::DeviceScan::InclusiveSum(temp.p, tb1, colptr.p + 1, colptr.p + 1, (int)n, c->stream));
+        if (nnz)
+            HIP_TRY(hipcub::DeviceRadixSort::SortPairs(temp.p, tb2, reinterpret_cast<const uint32_t *>(c->indices.p),
+                                                       reinterpret_cast<uint32_t *>(idx_sorted.p), c->data.p, vals_by_col.p, (int)nnz, 0, 32, c->stream));
+        hipLaunchKernelGGL(k_in_degree, dim3((unsigned)((n + tb - 1) / tb)), dim3(tb), 0, c->stream, colptr.p, vals_by_col.p, n, c->in_degree.p);
+        HIP_TRY(hipGetLastError());
+        vals_by_col.release(); idx_sorted.release();
+        if (fl[1]) {
+            // transition.py:65 sort_indices(): order the stored entries by (row, column)
+            HIP_TRY(keys_in.alloc(nnz));
+            HIP_TRY(keys_out.alloc(nnz));
+            HIP_TRY(data_sorted.alloc(nnz));
+            hipLaunchKernelGGL(k_csr_keys, dim3(row_blocks), dim3(BLOCK), 0, c->stream, c->indptr.p, c->indices.p, n, keys_in.p);
+            size_t tb3 = 0;
+            HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tb3, keys_in.p, keys_out.p, c->data.p, data_sorted.p, (int)nnz, 0, 64, c->stream));
+            if (tb3 > temp.count) HIP_TRY(temp.alloc(tb3));
+            HIP_TRY(hipcub::DeviceRadixSort::SortPairs(temp.p, tb3, keys_in.p, keys_out.p, c->data.p, data_sorted.p, (int)nnz, 0, 64, c->stream));
+            hipLaunchKernelGGL(k_split_keys, dim3((unsigned)((nnz + tb - 1) / tb)), dim3(tb), 0, c->stream, keys_out.p, nnz, c->indices.p);
+            HIP_TRY(hipMemcpyAsync(c->data.p, data_sorted.p, nnz * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+            HIP_TRY(hipMemsetAsync(flags.p, 0, 2 * sizeof(int32_t), c->stream));
+            hipLaunchKernelGGL(k_check_rows, dim3(row_blocks), dim3(BLOCK), 0, c->stream, c->indptr.p, c->indices.p, n, flags.p);
+            HIP_TRY(hipMemcpyAsync(fl, flags.p, sizeof(fl), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            if (fl[1]) return fail(ARCTE_HIP_EINVAL, "a row stores the same column twice (call sum_duplicates() first)");
+        }
+        // transition.py:61-63
+        hipLaunchKernelGGL(k_row_scale, dim3(row_blocks), dim3(BLOCK), 0, c->stream, c->indptr.p, c->out_degree.p, n, c->data.p);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        return 0;
+    }();
+    flags.release(); idx_sorted.release(); count.release(); colptr.release(); vals_by_col.release();
+    keys_in.release(); keys_out.release(); data_sorted.release(); temp.release();
+    return rc;
+}
+
 }  // namespace
 
 extern "C" {
@@ -373,28 +590,12 @@ int arcte_hip_create(int device, int64_t n, int64_t nnz, const int64_t *indptr, 
                 last_row[(size_t)indices[k]] = i;
             }
     }
-    int ndev = 0;
-    HIP_TRY(hipGetDeviceCount(&ndev));
-    if (device < 0 || device >= ndev) return fail(ARCTE_HIP_EHIP, "no such HIP device");
-    HIP_TRY(hipSetDevice(device));
-    arcte_hip_ctx *c = new arcte_hip_ctx();
-    c->device = device;
-    c->n = n;
-    c->nnz = nnz;
+    arcte_hip_ctx *c = nullptr;
+    int rc = ctx_begin(device, n, nnz, &c);
+    if (rc) return rc;
     c->row_len.resize((size_t)n);
     for (int64_t i = 0; i < n; i++) c->row_len[i] = (int32_t)std::min<int64_t>(indptr[i + 1] - indptr[i], INT32_MAX);
-    int rc = [&]() -> int {
-        hipDeviceProp_t prop;
-        HIP_TRY(hipGetDeviceProperties(&prop, device));
-        c->cus = prop.multiProcessorCount;
-        HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-        for (auto &e : c->ev) HIP_TRY(hipEventCreate(&e));
-        HIP_TRY(c->indptr.alloc(n + 1));
-        HIP_TRY(c->indices.alloc(nnz));
-        HIP_TRY(c->data.alloc(nnz));
-        HIP_TRY(c->out_degree.alloc(n));
-        HIP_TRY(c->in_degree.alloc(n));
-        HIP_TRY(c->edge_in_degree.alloc(nnz));
+    rc = [&]() -> int {
         HIP_TRY(hipMemcpyAsync(c->indptr.p, indptr, (n + 1) * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
         if (nnz) {
             HIP_TRY(hipMemcpyAsync(c->indices.p, indices, nnz * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
@@ -402,71 +603,7 @@ int arcte_hip_create(int device, int64_t n, int64_t nnz, const int64_t *indptr, 
         }
         HIP_TRY(hipMemcpyAsync(c->out_degree.p, out_degree, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipMemcpyAsync(c->in_degree.p, in_degree, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
-        if (nnz) {
-            hipLaunchKernelGGL(k_edge_in_degree, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, c->stream, c->indices.p,
-                               c->in_degree.p, c->edge_in_degree.p, nnz);
-            HIP_TRY(hipGetLastError());
-        }
-        HIP_TRY(c->counters.alloc(8));
-        // ---- hot table: rank the nodes by pattern in-degree (stable: ties keep the node order), the ranks stream
-        //      with the rows.  All on the device; the host never sees the ranking.
-        {
-            const int64_t ranked = std::min<int64_t>(n, (int64_t)HOT_NONE);
-            HIP_TRY(c->node_hot.alloc(n));
-            HIP_TRY(c->edge_hot.alloc(nnz));
-            HIP_TRY(hipMemsetAsync(c->node_hot.p, 0xFF, c->node_hot.bytes(), c->stream));
-            DevBuf<uint32_t> cnt, keys_in, keys_out;
-            DevBuf<int32_t> ids_in, ids_out;
-            DevBuf<char> temp;
-            int rk = [&]() -> int {
-                HIP_TRY(cnt.alloc(n));
-                HIP_TRY(keys_in.alloc(n));
-                HIP_TRY(keys_out.alloc(n));
-                HIP_TRY(ids_in.alloc(n));
-                HIP_TRY(ids_out.alloc(n));
-                HIP_TRY(hipMemsetAsync(cnt.p, 0, cnt.bytes(), c->stream));
-                const int tb = 256;
-                if (nnz) hipLaunchKernelGGL(k_column_counts, dim3((unsigned)((nnz + tb - 1) / tb)), dim3(tb), 0, c->stream, c->indices.p, nnz, cnt.p);
-                hipLaunchKernelGGL(k_rank_keys, dim3((unsigned)((n + tb - 1) / tb)), dim3(tb), 0, c->stream, cnt.p, n, keys_in.p, ids_in.p);
-                HIP_TRY(hipGetLastError());
-                size_t temp_bytes = 0;
-                HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, keys_in.p, keys_out.p, ids_in.p, ids_out.p, (int)n, 0, 32, c->stream));
-                HIP_TRY(temp.alloc(temp_bytes));
-                HIP_TRY(hipcub::DeviceRadixSort::SortPairs(temp.p, temp_bytes, keys_in.p, keys_out.p, ids_in.p, ids_out.p, (int)n, 0, 32, c->stream));
-                hipLaunchKernelGGL(k_assign_hot, dim3((unsigned)((ranked + tb - 1) / tb)), dim3(tb), 0, c->stream, ids_out.p, ranked, c->node_hot.p);
-                if (nnz) hipLaunchKernelGGL(k_edge_hot, dim3((unsigned)((nnz + tb - 1) / tb)), dim3(tb), 0, c->stream, c->indices.p, c->node_hot.p, c->edge_hot.p, nnz);
-                HIP_TRY(hipGetLastError());
-                HIP_TRY(hipStreamSynchronize(c->stream));
-                return 0;
-            }();
-            cnt.release(); keys_in.release(); keys_out.release(); ids_in.release(); ids_out.release(); temp.release();
-            if (rk) return rk;
-            c->hot_ranked = ranked;
-        }
-        // ---- launch shape.  The propagation kernel is bound by the chip's random-access rate into the per-slot HBM
-        //      state, and the LDS-resident hot table takes 20-40 % of those accesses away -- the more the fewer
-        //      wavefronts share a CU's LDS, while fewer wavefronts keep fewer accesses in flight.
-        c->waves_per_block = std::max(1, std::min(env_int("ARCTE_HIP_WAVES_PER_BLOCK", 1), WAVES_PER_BLOCK));
-        c->tiles = env_int("ARCTE_HIP_TILES", 2) == 4 ? 4 : 2;
-        const int wpb = c->waves_per_block;
-        int64_t slots = n_slots;
-        if (slots <= 0) {
-            c->waves_per_cu = std::max(1, std::min(env_int("ARCTE_HIP_WAVES_PER_CU", 4), 32));
-            slots = (int64_t)c->waves_per_cu * c->cus;
-            // keep the slot scratch within a fixed share of the device
-            size_t free_b = 0, total_b = 0;
-            HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-            size_t per_slot = (size_t)n * (sizeof(Entry) + sizeof(int32_t)) + (size_t)default_queue_capacity(n) * sizeof(QEntry);
-            while (slots > c->cus && (size_t)slots * per_slot > free_b / 4 * 3) slots -= c->cus / 2;
-        }
-        slots = std::max<int64_t>(wpb, (slots + wpb - 1) / wpb * wpb);
-        c->waves_per_cu = (int)std::max<int64_t>(1, std::min<int64_t>(32, (slots + c->cus - 1) / c->cus));
-        uint32_t qcap = queue_capacity > 0 ? next_pow2((uint64_t)queue_capacity) : default_queue_capacity(n);
-        if (qcap < (uint32_t)WAVE) qcap = WAVE;
-        int r = alloc_slots(c, slots, qcap);
-        if (r) return r;
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        return 0;
+        return ctx_finish(c, n_slots, queue_capacity);
     }();
     if (rc) {
         std::string keep = g_err;
@@ -478,13 +615,188 @@ int arcte_hip_create(int device, int64_t n, int64_t nnz, const int64_t *indptr, 
     return 0;
 }
 
+
+// ---- device-side graph preparation -------------------------------------------------------------
+
+int arcte_hip_create_from_adjacency(int device, int64_t n, int64_t nnz, const int64_t *indptr, const int32_t *indices,
+                                    const double *data, int64_t n_slots, int64_t queue_capacity, arcte_hip_ctx **out)
+{
+    if (!out) return fail(ARCTE_HIP_EINVAL, "out is NULL");
+    *out = nullptr;
+    if (n <= 0 || n >= (int64_t)1 << 31 || nnz < 0 || nnz >= (int64_t)1 << 31) return fail(ARCTE_HIP_EINVAL, "n must be in [1, 2^31), nnz in [0, 2^31)");
+    if (!indptr || (nnz > 0 && (!indices || !data))) return fail(ARCTE_HIP_EINVAL, "NULL graph array");
+    if (indptr[0] != 0 || indptr[n] != nnz) return fail(ARCTE_HIP_EINVAL, "indptr does not span [0, nnz]");
+    for (int64_t i = 0; i < n; i++)
+        if (indptr[i + 1] < indptr[i]) return fail(ARCTE_HIP_EINVAL, "indptr is not monotone");
+    arcte_hip_ctx *c = nullptr;
+    int rc = ctx_begin(device, n, nnz, &c);
+    if (rc) return rc;
+    c->row_len.resize((size_t)n);
+    for (int64_t i = 0; i < n; i++) c->row_len[i] = (int32_t)std::min<int64_t>(indptr[i + 1] - indptr[i], INT32_MAX);
+    rc = [&]() -> int {
+        HIP_TRY(hipMemcpyAsync(c->indptr.p, indptr, (n + 1) * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
+        if (nnz) {
+            HIP_TRY(hipMemcpyAsync(c->indices.p, indices, nnz * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipMemcpyAsync(c->data.p, data, nnz * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        }
+        int r = transition_on_device(c);
+        if (r) return r;
+        return ctx_finish(c, n_slots, queue_capacity);
+    }();
+    if (rc) {
+        std::string keep = g_err;
+        arcte_hip_destroy(c);
+        g_err = keep;
+        return rc;
+    }
+    *out = c;
+    return 0;
+}
+
+int arcte_hip_create_from_coo(int device, int64_t n, int64_t nnz, const int32_t *row, const int32_t *col, const double *val,
+                              int symmetrise, int64_t n_slots, int64_t queue_capacity, arcte_hip_ctx **out)
+{
+    if (!out) return fail(ARCTE_HIP_EINVAL, "out is NULL");
+    *out = nullptr;
+    if (n <= 0 || n >= (int64_t)1 << 31 || nnz < 0 || nnz >= (int64_t)1 << 30) return fail(ARCTE_HIP_EINVAL, "n must be in [1, 2^31), nnz in [0, 2^30)");
+    if (nnz > 0 && (!row || !col || !val)) return fail(ARCTE_HIP_EINVAL, "NULL triplet array");
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail(ARCTE_HIP_EHIP, "no such HIP device");
+    HIP_TRY(hipSetDevice(device));
+    const int tb = 256;
+    DevBuf<int32_t> row_d, col_d, flags, rows_u, idx_u;
+    DevBuf<double> val_d, vals, vals_sorted, data_u;
+    DevBuf<uint64_t> keys, keys_sorted;
+    DevBuf<int64_t> head;
+    DevBuf<char> temp;
+    arcte_hip_ctx *c = nullptr;
+    // Stage 1: the triplets become a canonical CSR -- csr_matrix(coo) sums duplicate entries (here: in input order).
+    // Stage 2 (symmetrise): (A + A^T)/2 of entry_points/arcte.py:70-71: the canonical entries and their mirror
+    // images are merged the same way (at most two per position, a + b is exact in either order) and halved.
+    auto canonicalise = [&](const uint64_t *keys_in, const double *vals_in, int64_t m, double scale, int64_t *unique_out) -> int {
+        // sort (stable) -> head flags -> positions -> merged entries in rows_u / idx_u / data_u
+        HIP_TRY(keys_sorted.reserve(m));
+        HIP_TRY(vals_sorted.reserve(m));
+        HIP_TRY(head.reserve(m));
+        size_t t1 = 0, t2 = 0;
+        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, t1, keys_in, keys_sorted.p, vals_in, vals_sorted.p, (int)m, 0, 64, 0));
+        HIP_TRY(hipcub::DeviceScan::InclusiveSum(nullptr, t2, head.p, head.p, (int)m, 0));
+        HIP_TRY(temp.reserve(std::max(t1, t2)));
+        if (m == 0) { *unique_out = 0; return 0; }
+        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(temp.p, t1, keys_in, keys_sorted.p, vals_in, vals_sorted.p, (int)m, 0, 64, 0));
+        hipLaunchKernelGGL(k_head_flags, dim3((unsigned)((m + tb - 1) / tb)), dim3(tb), 0, 0, keys_sorted.p, m, head.p);
+        HIP_TRY(hipcub::DeviceScan::InclusiveSum(temp.p, t2, head.p, head.p, (int)m, 0));
+        int64_t uniq = 0;
+        HIP_TRY(hipMemcpy(&uniq, head.p + (m - 1), sizeof(int64_t), hipMemcpyDeviceToHost));
+        HIP_TRY(rows_u.reserve(uniq));
+        HIP_TRY(idx_u.reserve(uniq));
+        HIP_TRY(data_u.reserve(uniq));
+        hipLaunchKernelGGL(k_merge_duplicates, dim3((unsigned)((m + tb - 1) / tb)), dim3(tb), 0, 0, keys_sorted.p, vals_sorted.p, head.p, m,
+                           scale, idx_u.p, data_u.p, rows_u.p);
+        HIP_TRY(hipGetLastError());
+        *unique_out = uniq;
+        return 0;
+    };
+    int rc = [&]() -> int {
+        HIP_TRY(row_d.alloc(nnz));
+        HIP_TRY(col_d.alloc(nnz));
+        HIP_TRY(val_d.alloc(nnz));
+        HIP_TRY(flags.alloc(2));
+        HIP_TRY(keys.alloc(2 * nnz));
+        HIP_TRY(vals.alloc(2 * nnz));
+        HIP_TRY(hipMemset(flags.p, 0, 2 * sizeof(int32_t)));
+        if (nnz) {
+            HIP_TRY(hipMemcpy(row_d.p, row, nnz * sizeof(int32_t), hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(col_d.p, col, nnz * sizeof(int32_t), hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(val_d.p, val, nnz * sizeof(double), hipMemcpyHostToDevice));
+            hipLaunchKernelGGL(k_coo_keys, dim3((unsigned)((nnz + tb - 1) / tb)), dim3(tb), 0, 0, row_d.p, col_d.p, val_d.p, nnz, 0, n,
+                               keys.p, vals.p, flags.p);
+            HIP_TRY(hipGetLastError());
+        }
+        int32_t fl[2] = {0, 0};
+        HIP_TRY(hipMemcpy(fl, flags.p, sizeof(fl), hipMemcpyDeviceToHost));
+        if (fl[0]) return fail(ARCTE_HIP_EINVAL, "triplet index out of range");
+        int64_t uniq = 0;
+        int r = canonicalise(keys.p, vals.p, nnz, 1.0, &uniq);
+        if (r) return r;
+        if (symmetrise && uniq) {
+            // the canonical entries (rows_u, idx_u, data_u) and their mirror images
+            HIP_TRY(keys.reserve(2 * uniq));
+            HIP_TRY(vals.reserve(2 * uniq));
+            hipLaunchKernelGGL(k_coo_keys, dim3((unsigned)((uniq + tb - 1) / tb)), dim3(tb), 0, 0, rows_u.p, idx_u.p, data_u.p, uniq, 1, n,
+                               keys.p, vals.p, flags.p);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipDeviceSynchronize());
+            r = canonicalise(keys.p, vals.p, 2 * uniq, 0.5, &uniq);
+            if (r) return r;
+        }
+        r = ctx_begin(device, n, uniq, &c);
+        if (r) return r;
+        hipLaunchKernelGGL(k_rows_to_indptr, dim3((unsigned)((n + 1 + tb - 1) / tb)), dim3(tb), 0, 0, rows_u.p, uniq, n, c->indptr.p);
+        HIP_TRY(hipGetLastError());
+        if (uniq) {
+            HIP_TRY(hipMemcpy(c->indices.p, idx_u.p, uniq * sizeof(int32_t), hipMemcpyDeviceToDevice));
+            HIP_TRY(hipMemcpy(c->data.p, data_u.p, uniq * sizeof(double), hipMemcpyDeviceToDevice));
+        }
+        HIP_TRY(hipDeviceSynchronize());
+        return 0;
+    }();
+    row_d.release(); col_d.release(); val_d.release(); flags.release(); rows_u.release(); idx_u.release();
+    vals.release(); vals_sorted.release(); data_u.release(); keys.release(); keys_sorted.release(); head.release(); temp.release();
+    if (!rc) {
+        rc = transition_on_device(c);
+        if (!rc) rc = ctx_finish(c, n_slots, queue_capacity);
+    }
+    if (rc) {
+        std::string keep = g_err;
+        if (c) arcte_hip_destroy(c);
+        g_err = keep;
+        return rc;
+    }
+    *out = c;
+    return 0;
+}
+
+int arcte_hip_graph_sizes(arcte_hip_ctx *c, int64_t *n, int64_t *nnz, int64_t *nseeds)
+{
+    if (!c) return fail(ARCTE_HIP_EINVAL, "ctx is NULL");
+    if (n) *n = c->n;
+    if (nnz) *nnz = c->nnz;
+    if (nseeds) *nseeds = c->nseeds_all;
+    return 0;
+}
+
+int arcte_hip_fetch_transition(arcte_hip_ctx *c, int64_t *indptr, int32_t *indices, double *data, double *out_degree,
+                               double *in_degree)
+{
+    if (!c) return fail(ARCTE_HIP_EINVAL, "ctx is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    if (indptr) HIP_TRY(hipMemcpy(indptr, c->indptr.p, (c->n + 1) * sizeof(int64_t), hipMemcpyDeviceToHost));
+    if (indices && c->nnz) HIP_TRY(hipMemcpy(indices, c->indices.p, c->nnz * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (data && c->nnz) HIP_TRY(hipMemcpy(data, c->data.p, c->nnz * sizeof(double), hipMemcpyDeviceToHost));
+    if (out_degree) HIP_TRY(hipMemcpy(out_degree, c->out_degree.p, c->n * sizeof(double), hipMemcpyDeviceToHost));
+    if (in_degree) HIP_TRY(hipMemcpy(in_degree, c->in_degree.p, c->n * sizeof(double), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int arcte_hip_fetch_seed_list(arcte_hip_ctx *c, int64_t *seeds)
+{
+    if (!c || (!seeds && c->nseeds_all)) return fail(ARCTE_HIP_EINVAL, "bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    std::vector<int32_t> tmp((size_t)std::max<int64_t>(c->nseeds_all, 1));
+    if (c->nseeds_all) HIP_TRY(hipMemcpy(tmp.data(), c->ranked_ids.p, c->nseeds_all * sizeof(int32_t), hipMemcpyDeviceToHost));
+    for (int64_t k = 0; k < c->nseeds_all; k++) seeds[k] = tmp[k];
+    return 0;
+}
+
 int arcte_hip_destroy(arcte_hip_ctx *c)
 {
     if (!c) return 0;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     c->indptr.release(); c->indices.release(); c->data.release(); c->out_degree.release(); c->in_degree.release();
-    c->state.release(); c->slot_epoch.release(); c->node_hot.release(); c->edge_hot.release(); c->edge_in_degree.release(); c->data_f.release(); c->in_degree_f.release(); c->edge_in_degree_f.release(); c->queue.release(); c->sup.release();
+    c->state.release(); c->slot_epoch.release(); c->ranked_ids.release(); c->node_hot.release(); c->edge_hot.release(); c->edge_in_degree.release(); c->data_f.release(); c->in_degree_f.release(); c->edge_in_degree_f.release(); c->queue.release(); c->sup.release();
     c->seeds_d.release(); c->work_pos.release(); c->out_cnt.release(); c->status.release(); c->nop_d.release();
     c->eps_d.release(); c->out_off.release(); c->dst_off.release(); c->counters.release();
     c->raw.release(); c->rows_final.release(); c->sort_keys.release(); c->sort_iota.release(); c->sort_temp.release(); c->eps_big_pos.release(); c->sort_keys_in.release();
@@ -854,60 +1166,100 @@ int arcte_hip_result_csr_size(arcte_hip_ctx *c, int with_base_block, int64_t *nn
     return 0;
 }
 
-int arcte_hip_fetch_result_csr(arcte_hip_ctx *c, int with_base_block, int64_t *indptr, int32_t *indices, int64_t *nnz_out)
+// The last run as CSR on the device: indptr_d[n+1], cols (uint32 column ids, the first *valid of them).
+static int assemble_csr_device(arcte_hip_ctx *c, int with_base_block, DevBuf<int64_t> &indptr_d, DevBuf<uint32_t> &cols, int64_t *valid_out)
 {
-    if (!c || !indptr || !nnz_out) return fail(ARCTE_HIP_EINVAL, "bad argument");
     if (c->run_nseeds < 0) return fail(ARCTE_HIP_ESTATE, "no completed run on this context");
     HIP_TRY(hipSetDevice(c->device));
     const int64_t n = c->n, ns = c->run_nseeds;
     const int64_t nbase = with_base_block ? c->nnz + n : 0;
     const int64_t nkeys = nbase + c->final_rows;
-    int64_t key_limit = (int64_t)1 << 31;
     if (const char *env = getenv("ARCTE_HIP_MAX_SORT_KEYS")) {      // test hook: force the host-assembly fallback
         long long v = atoll(env);
-        if (v > 0) key_limit = std::min<int64_t>(key_limit, v);
+        if (v > 0 && nkeys >= v) return fail(ARCTE_HIP_ECAPACITY, "too many entries for the device assembly (test hook): assemble on the host instead");
     }
-    if (nkeys >= key_limit) return fail(ARCTE_HIP_ECAPACITY, "too many entries for the device key sort: assemble on the host instead");
-    if (nkeys && !indices) return fail(ARCTE_HIP_EINVAL, "indices is NULL");
-    DevBuf<uint64_t> keys_a, keys_b;
-    DevBuf<int64_t> colptr_d, indptr_d;
-    DevBuf<int32_t> indices_d;
+    // the seeds in ascending id order: the local pairs are written seed by seed in that order, so every row's
+    // columns are ascending before the (stable) sort by row
+    std::vector<int32_t> seeds_h((size_t)std::max<int64_t>(ns, 1)), seg_of((size_t)std::max<int64_t>(ns, 1));
+    std::vector<int64_t> dst((size_t)std::max<int64_t>(ns, 1));
+    if (ns) HIP_TRY(hipMemcpy(seeds_h.data(), c->seeds_d.p, ns * sizeof(int32_t), hipMemcpyDeviceToHost));
+    for (int64_t k = 0; k < ns; k++) seg_of[(size_t)k] = (int32_t)k;
+    std::stable_sort(seg_of.begin(), seg_of.begin() + ns, [&](int32_t a, int32_t b) { return seeds_h[(size_t)a] < seeds_h[(size_t)b]; });
+    for (int64_t j = 1; j < ns; j++)
+        if (seeds_h[(size_t)seg_of[(size_t)j]] == seeds_h[(size_t)seg_of[(size_t)j - 1]])
+            return fail(ARCTE_HIP_EINVAL, "the run listed a seed twice: its column would hold duplicate entries");
+    {
+        int64_t o = nbase;
+        for (int64_t j = 0; j < ns; j++) {
+            dst[(size_t)j] = o;
+            o += c->colptr[(size_t)seg_of[(size_t)j] + 1] - c->colptr[(size_t)seg_of[(size_t)j]];
+        }
+    }
+    DevBuf<uint32_t> key_a, key_b, val_a;
+    DevBuf<int64_t> colptr_d, dst_d;
+    DevBuf<int32_t> seg_d;
     DevBuf<char> temp;
     int rc = [&]() -> int {
-        HIP_TRY(keys_a.alloc(nkeys));
-        HIP_TRY(keys_b.alloc(nkeys));
+        HIP_TRY(key_a.alloc(nkeys));
+        HIP_TRY(key_b.alloc(nkeys));
+        HIP_TRY(val_a.alloc(nkeys));
+        HIP_TRY(cols.alloc(nkeys));
         HIP_TRY(indptr_d.alloc(n + 1));
-        HIP_TRY(indices_d.alloc(nkeys));
         HIP_TRY(colptr_d.alloc(ns + 1));
+        HIP_TRY(dst_d.alloc(ns));
+        HIP_TRY(seg_d.alloc(ns));
         HIP_TRY(hipMemcpyAsync(colptr_d.p, c->colptr.data(), (ns + 1) * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
+        if (ns) {
+            HIP_TRY(hipMemcpyAsync(dst_d.p, dst.data(), ns * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipMemcpyAsync(seg_d.p, seg_of.data(), ns * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+        }
         if (with_base_block) {
             int blocks = (int)((n + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
-            hipLaunchKernelGGL(k_keys_base, dim3(blocks), dim3(BLOCK), 0, c->stream, c->indptr.p, c->indices.p, n, keys_a.p);
+            hipLaunchKernelGGL(k_pairs_base, dim3(blocks), dim3(BLOCK), 0, c->stream, c->indptr.p, c->indices.p, n, key_a.p, val_a.p);
         }
         if (ns && c->final_rows) {
             int blocks = (int)((ns + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
-            hipLaunchKernelGGL(k_keys_local, dim3(blocks), dim3(BLOCK), 0, c->stream, c->rows_final.p, colptr_d.p, c->seeds_d.p, ns,
-                               with_base_block ? (uint32_t)n : 0u, keys_a.p + nbase);
+            hipLaunchKernelGGL(k_pairs_local, dim3(blocks), dim3(BLOCK), 0, c->stream, c->rows_final.p, colptr_d.p, c->seeds_d.p, seg_d.p,
+                               dst_d.p, ns, with_base_block ? (uint32_t)n : 0u, key_a.p, val_a.p);
         }
         HIP_TRY(hipGetLastError());
-        const int end_bit = 64;   // dropped identity entries carry all-ones keys and must sort last
+        int end_bit = 1;                      // row ids 0 .. n (n = dropped identity entries, sorted to the end)
+        while (end_bit < 32 && ((uint64_t)1 << end_bit) <= (uint64_t)n) end_bit++;
         size_t temp_bytes = 0;
-        HIP_TRY(hipcub::DeviceRadixSort::SortKeys(nullptr, temp_bytes, keys_a.p, keys_b.p, (int)nkeys, 0, end_bit, c->stream));
+        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, key_a.p, key_b.p, val_a.p, cols.p, (size_t)nkeys, 0, end_bit, c->stream));
         HIP_TRY(temp.alloc(temp_bytes));
-        if (nkeys) HIP_TRY(hipcub::DeviceRadixSort::SortKeys(temp.p, temp_bytes, keys_a.p, keys_b.p, (int)nkeys, 0, end_bit, c->stream));
+        if (nkeys) HIP_TRY(hipcub::DeviceRadixSort::SortPairs(temp.p, temp_bytes, key_a.p, key_b.p, val_a.p, cols.p, (size_t)nkeys, 0, end_bit, c->stream));
         const int tb = 256;
-        const int64_t work = std::max<int64_t>(nkeys, n + 1);
-        hipLaunchKernelGGL(k_keys_to_csr, dim3((unsigned)((work + tb - 1) / tb)), dim3(tb), 0, c->stream, keys_b.p, nkeys, n,
-                           indices_d.p, indptr_d.p);
+        hipLaunchKernelGGL(k_rows_to_indptr_u32, dim3((unsigned)((n + 1 + tb - 1) / tb)), dim3(tb), 0, c->stream, key_b.p, nkeys, n, indptr_d.p);
         HIP_TRY(hipGetLastError());
+        int64_t valid = 0;                    // pairs with row id n (dropped identity entries) sit behind row n-1
+        HIP_TRY(hipMemcpyAsync(&valid, indptr_d.p + n, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
-        HIP_TRY(hipMemcpy(indptr, indptr_d.p, (n + 1) * sizeof(int64_t), hipMemcpyDeviceToHost));
-        const int64_t valid = indptr[n];          // all-ones keys (dropped identity entries) sit behind row n-1
-        if (valid) HIP_TRY(hipMemcpy(indices, indices_d.p, valid * sizeof(int32_t), hipMemcpyDeviceToHost));
+        *valid_out = valid;
+        return 0;
+    }();
+    key_a.release(); key_b.release(); val_a.release(); colptr_d.release(); dst_d.release(); seg_d.release(); temp.release();
+    return rc;
+}
+
+int arcte_hip_fetch_result_csr(arcte_hip_ctx *c, int with_base_block, int64_t *indptr, int32_t *indices, int64_t *nnz_out)
+{
+    if (!c || !indptr || !nnz_out) return fail(ARCTE_HIP_EINVAL, "bad argument");
+    DevBuf<int64_t> indptr_d;
+    DevBuf<uint32_t> cols;
+    int64_t valid = 0;
+    int rc = assemble_csr_device(c, with_base_block, indptr_d, cols, &valid);
+    if (!rc) rc = [&]() -> int {
+        if (valid && !indices) return fail(ARCTE_HIP_EINVAL, "indices is NULL");
+        HIP_TRY(hipMemcpy(indptr, indptr_d.p, (c->n + 1) * sizeof(int64_t), hipMemcpyDeviceToHost));
+        // the column ids go out in pieces, so that the pageable destination is faulted in while the next piece moves
+        const int64_t piece = (int64_t)64 << 20;
+        for (int64_t o = 0; o < valid; o += piece)
+            HIP_TRY(hipMemcpy(indices + o, cols.p + o, std::min(piece, valid - o) * sizeof(int32_t), hipMemcpyDeviceToHost));
         *nnz_out = valid;
         return 0;
     }();
-    keys_a.release(); keys_b.release(); colptr_d.release(); indptr_d.release(); indices_d.release(); temp.release();
+    indptr_d.release(); cols.release();
     return rc;
 }
 
@@ -1110,6 +1462,318 @@ int arcte_hip_push_variant(int device, int64_t n, double *s, double *r, const do
     return push_impl(device, n, s, r, w_i, a_i, deg, push_node, rho, variant, laziness_factor);
 }
 
+// ---- device-resident feature matrices ----------------------------------------------------------
+
+struct arcte_hip_features {
+    int device = 0;
+    int64_t n_rows = 0, n_cols = 0, nnz = 0;
+    DevBuf<int64_t> indptr;
+    DevBuf<int32_t> indices;
+    DevBuf<double> data;
+};
+
+static int column_counts(arcte_hip_features *f, DevBuf<uint32_t> &count)
+{
+    HIP_TRY(count.alloc(f->n_cols));
+    HIP_TRY(hipMemset(count.p, 0, count.bytes()));
+    if (f->nnz) hipLaunchKernelGGL(k_feat_column_counts, dim3((unsigned)((f->nnz + 255) / 256)), dim3(256), 0, 0, f->indices.p, f->nnz, count.p);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int arcte_hip_features_destroy(arcte_hip_features *f)
+{
+    if (!f) return 0;
+    (void)hipSetDevice(f->device);
+    f->indptr.release(); f->indices.release(); f->data.release();
+    delete f;
+    return 0;
+}
+
+int arcte_hip_features_upload(int device, int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t *indptr, const int32_t *indices,
+                              const double *data, arcte_hip_features **out)
+{
+    if (!out) return fail(ARCTE_HIP_EINVAL, "out is NULL");
+    *out = nullptr;
+    if (n_rows < 0 || n_cols <= 0 || n_cols >= ((int64_t)1 << 31) || nnz < 0 || !indptr || (nnz && (!indices || !data)))
+        return fail(ARCTE_HIP_EINVAL, "bad argument");
+    if (indptr[0] != 0 || indptr[n_rows] != nnz) return fail(ARCTE_HIP_EINVAL, "indptr does not span [0, nnz]");
+    for (int64_t k = 0; k < nnz; k++)
+        if (indices[k] < 0 || indices[k] >= n_cols) return fail(ARCTE_HIP_EINVAL, "column index out of range");
+    HIP_TRY(hipSetDevice(device));
+    arcte_hip_features *f = new arcte_hip_features();
+    f->device = device; f->n_rows = n_rows; f->n_cols = n_cols; f->nnz = nnz;
+    int rc = [&]() -> int {
+        HIP_TRY(f->indptr.alloc(n_rows + 1));
+        HIP_TRY(f->indices.alloc(nnz));
+        HIP_TRY(f->data.alloc(nnz));
+        HIP_TRY(hipMemcpy(f->indptr.p, indptr, (n_rows + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+        if (nnz) {
+            HIP_TRY(hipMemcpy(f->indices.p, indices, nnz * sizeof(int32_t), hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(f->data.p, data, nnz * sizeof(double), hipMemcpyHostToDevice));
+        }
+        return 0;
+    }();
+    if (rc) { std::string keep = g_err; arcte_hip_features_destroy(f); g_err = keep; return rc; }
+    *out = f;
+    return 0;
+}
+
+// value of every stored entry of arcte()'s matrix: 1.0, and 2.0 on the diagonal of a node with a self-loop (I + ones)
+__global__ __launch_bounds__(BLOCK) void k_feat_values_of_result(const int64_t *w_indptr, const int32_t *w_indices, const int64_t *indptr,
+                                                                 const int32_t *indices, int64_t n, int with_base_block, double *data)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const int64_t b = indptr[i], e = indptr[i + 1];
+    for (int64_t k = b + lane; k < e; k += WAVE) data[k] = 1.0;
+    if (!with_base_block) return;
+    bool loop = false;
+    for (int64_t k = w_indptr[i] + lane; k < w_indptr[i + 1]; k += WAVE) loop |= (w_indices[k] == (int32_t)i);
+    if (__ballot(loop) == 0) return;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    for (int64_t k = b + lane; k < e; k += WAVE)
+        if (indices[k] == (int32_t)i) data[k] = 2.0;
+}
+
+int arcte_hip_features_from_result(arcte_hip_ctx *c, int with_base_block, arcte_hip_features **out)
+{
+    if (!c || !out) return fail(ARCTE_HIP_EINVAL, "bad argument");
+    *out = nullptr;
+    DevBuf<int64_t> indptr_d;
+    DevBuf<uint32_t> cols;
+    int64_t valid = 0;
+    int rc = assemble_csr_device(c, with_base_block, indptr_d, cols, &valid);
+    if (rc) { indptr_d.release(); cols.release(); return rc; }
+    arcte_hip_features *f = new arcte_hip_features();
+    f->device = c->device; f->n_rows = c->n; f->n_cols = with_base_block ? 2 * c->n : c->n; f->nnz = valid;
+    f->indptr = indptr_d; indptr_d.p = nullptr;
+    f->indices.p = reinterpret_cast<int32_t *>(cols.p); f->indices.count = (size_t)valid; f->indices.capacity = cols.capacity; cols.p = nullptr;
+    rc = [&]() -> int {
+        HIP_TRY(f->data.alloc(valid));
+        int blocks = (int)((c->n + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
+        hipLaunchKernelGGL(k_feat_values_of_result, dim3(blocks), dim3(BLOCK), 0, c->stream, c->indptr.p, c->indices.p, f->indptr.p, f->indices.p,
+                           c->n, with_base_block, f->data.p);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        return 0;
+    }();
+    if (rc) { std::string keep = g_err; arcte_hip_features_destroy(f); g_err = keep; return rc; }
+    *out = f;
+    return 0;
+}
+
+int arcte_hip_features_sizes(arcte_hip_features *f, int64_t *n_rows, int64_t *n_cols, int64_t *nnz)
+{
+    if (!f) return fail(ARCTE_HIP_EINVAL, "features is NULL");
+    if (n_rows) *n_rows = f->n_rows;
+    if (n_cols) *n_cols = f->n_cols;
+    if (nnz) *nnz = f->nnz;
+    return 0;
+}
+
+int arcte_hip_features_fetch(arcte_hip_features *f, int64_t *indptr, int32_t *indices, double *data)
+{
+    if (!f) return fail(ARCTE_HIP_EINVAL, "features is NULL");
+    HIP_TRY(hipSetDevice(f->device));
+    if (indptr) HIP_TRY(hipMemcpy(indptr, f->indptr.p, (f->n_rows + 1) * sizeof(int64_t), hipMemcpyDeviceToHost));
+    if (indices && f->nnz) HIP_TRY(hipMemcpy(indices, f->indices.p, f->nnz * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (data && f->nnz) HIP_TRY(hipMemcpy(data, f->data.p, f->nnz * sizeof(double), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int arcte_hip_features_normalize_columns(arcte_hip_features *f)
+{
+    if (!f) return fail(ARCTE_HIP_EINVAL, "features is NULL");
+    HIP_TRY(hipSetDevice(f->device));
+    DevBuf<uint32_t> count;
+    DevBuf<double> divisor;
+    int rc = [&]() -> int {
+        int r = column_counts(f, count);
+        if (r) return r;
+        HIP_TRY(divisor.alloc(f->n_cols));
+        hipLaunchKernelGGL(k_feat_idf, dim3((unsigned)((f->n_cols + 255) / 256)), dim3(256), 0, 0, count.p, f->n_cols, divisor.p);
+        if (f->nnz) hipLaunchKernelGGL(k_feat_divide_columns, dim3((unsigned)((f->nnz + 255) / 256)), dim3(256), 0, 0, f->indices.p, divisor.p, f->nnz, f->data.p);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipDeviceSynchronize());
+        return 0;
+    }();
+    count.release(); divisor.release();
+    return rc;
+}
+
+int arcte_hip_features_normalize_rows(arcte_hip_features *f)
+{
+    if (!f) return fail(ARCTE_HIP_EINVAL, "features is NULL");
+    HIP_TRY(hipSetDevice(f->device));
+    if (f->n_rows) hipLaunchKernelGGL(k_feat_normalize_rows, dim3((unsigned)((f->n_rows + 255) / 256)), dim3(256), 0, 0, f->indptr.p, f->n_rows, f->data.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    return 0;
+}
+
+int arcte_hip_features_community_weighting(arcte_hip_features *f, const double *community_weights)
+{
+    if (!f || !community_weights) return fail(ARCTE_HIP_EINVAL, "bad argument");
+    HIP_TRY(hipSetDevice(f->device));
+    DevBuf<uint32_t> count;
+    DevBuf<double> w_d, factor, data_out;
+    DevBuf<int64_t> pos, indptr_out;
+    DevBuf<int32_t> indices_out;
+    DevBuf<char> temp;
+    int rc = [&]() -> int {
+        int r = column_counts(f, count);
+        if (r) return r;
+        HIP_TRY(w_d.alloc(f->n_cols));
+        HIP_TRY(factor.alloc(f->n_cols));
+        HIP_TRY(hipMemcpy(w_d.p, community_weights, f->n_cols * sizeof(double), hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_feat_reinforcement, dim3((unsigned)((f->n_cols + 255) / 256)), dim3(256), 0, 0, count.p, w_d.p, f->n_cols, factor.p);
+        if (f->nnz) {
+            hipLaunchKernelGGL(k_feat_multiply_columns, dim3((unsigned)((f->nnz + 255) / 256)), dim3(256), 0, 0, f->indices.p, factor.p, f->nnz, f->data.p);
+            // eliminate_zeros() (:115-116)
+            HIP_TRY(pos.alloc(f->nnz));
+            hipLaunchKernelGGL(k_feat_nonzero_flags, dim3((unsigned)((f->nnz + 255) / 256)), dim3(256), 0, 0, f->data.p, f->nnz, pos.p);
+            size_t tb = 0;
+            HIP_TRY(hipcub::DeviceScan::InclusiveSum(nullptr, tb, pos.p, pos.p, (int)f->nnz, 0));
+            HIP_TRY(temp.alloc(tb));
+            HIP_TRY(hipcub::DeviceScan::InclusiveSum(temp.p, tb, pos.p, pos.p, (int)f->nnz, 0));
+            int64_t kept = 0;
+            HIP_TRY(hipMemcpy(&kept, pos.p + (f->nnz - 1), sizeof(int64_t), hipMemcpyDeviceToHost));
+            if (kept != f->nnz) {
+                HIP_TRY(indices_out.alloc(kept));
+                HIP_TRY(data_out.alloc(kept));
+                HIP_TRY(indptr_out.alloc(f->n_rows + 1));
+                hipLaunchKernelGGL(k_feat_compact, dim3((unsigned)((f->nnz + 255) / 256)), dim3(256), 0, 0, f->indices.p, f->data.p, pos.p, f->nnz,
+                                   indices_out.p, data_out.p);
+                hipLaunchKernelGGL(k_feat_compact_indptr, dim3((unsigned)((f->n_rows + 1 + 255) / 256)), dim3(256), 0, 0, f->indptr.p, pos.p, f->n_rows,
+                                   indptr_out.p);
+                HIP_TRY(hipGetLastError());
+                HIP_TRY(hipDeviceSynchronize());
+                f->indices.release(); f->data.release(); f->indptr.release();
+                f->indices = indices_out; indices_out.p = nullptr;
+                f->data = data_out; data_out.p = nullptr;
+                f->indptr = indptr_out; indptr_out.p = nullptr;
+                f->nnz = kept;
+            }
+        }
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }();
+    count.release(); w_d.release(); factor.release(); data_out.release(); pos.release(); indptr_out.release(); indices_out.release(); temp.release();
+    if (rc) return rc;
+    return arcte_hip_features_normalize_rows(f);        // :118-119
+}
+
+int arcte_hip_features_select_rows(arcte_hip_features *f, const int64_t *rows, int64_t nsel, arcte_hip_features **out)
+{
+    if (!f || !out || nsel < 0 || (nsel && !rows)) return fail(ARCTE_HIP_EINVAL, "bad argument");
+    *out = nullptr;
+    for (int64_t i = 0; i < nsel; i++)
+        if (rows[i] < 0 || rows[i] >= f->n_rows) return fail(ARCTE_HIP_EINVAL, "row index out of range");
+    HIP_TRY(hipSetDevice(f->device));
+    arcte_hip_features *g = new arcte_hip_features();
+    g->device = f->device; g->n_rows = nsel; g->n_cols = f->n_cols;
+    DevBuf<int64_t> rows_d;
+    DevBuf<char> temp;
+    int rc = [&]() -> int {
+        HIP_TRY(rows_d.alloc(nsel));
+        HIP_TRY(g->indptr.alloc(nsel + 1));
+        HIP_TRY(hipMemset(g->indptr.p, 0, sizeof(int64_t)));
+        if (nsel) {
+            HIP_TRY(hipMemcpy(rows_d.p, rows, nsel * sizeof(int64_t), hipMemcpyHostToDevice));
+            hipLaunchKernelGGL(k_feat_selected_lengths, dim3((unsigned)((nsel + 255) / 256)), dim3(256), 0, 0, f->indptr.p, rows_d.p, nsel, g->indptr.p + 1);
+            size_t tb = 0;
+            HIP_TRY(hipcub::DeviceScan::InclusiveSum(nullptr, tb, g->indptr.p + 1, g->indptr.p + 1, (int)nsel, 0));
+            HIP_TRY(temp.alloc(tb));
+            HIP_TRY(hipcub::DeviceScan::InclusiveSum(temp.p, tb, g->indptr.p + 1, g->indptr.p + 1, (int)nsel, 0));
+        }
+        int64_t nnz = 0;
+        HIP_TRY(hipMemcpy(&nnz, g->indptr.p + nsel, sizeof(int64_t), hipMemcpyDeviceToHost));
+        g->nnz = nnz;
+        HIP_TRY(g->indices.alloc(nnz));
+        HIP_TRY(g->data.alloc(nnz));
+        if (nsel) {
+            int blocks = (int)((nsel + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
+            hipLaunchKernelGGL(k_feat_copy_rows, dim3(blocks), dim3(BLOCK), 0, 0, f->indptr.p, f->indices.p, f->data.p, rows_d.p, nsel, g->indptr.p,
+                               g->indices.p, g->data.p);
+        }
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipDeviceSynchronize());
+        return 0;
+    }();
+    rows_d.release(); temp.release();
+    if (rc) { std::string keep = g_err; arcte_hip_features_destroy(g); g_err = keep; return rc; }
+    *out = g;
+    return 0;
+}
+
+int arcte_hip_features_chi2_psnr_weights(arcte_hip_features *f, const int64_t *y_indptr, const int32_t *y_indices, int64_t n_classes,
+                                         double *contingency_out, double *weights_out)
+{
+    if (!f || !y_indptr || n_classes <= 0 || !weights_out) return fail(ARCTE_HIP_EINVAL, "bad argument");
+    const int64_t ny = y_indptr[f->n_rows];
+    if (ny && !y_indices) return fail(ARCTE_HIP_EINVAL, "y_indices is NULL");
+    for (int64_t k = 0; k < ny; k++)
+        if (y_indices[k] < 0 || y_indices[k] >= n_classes) return fail(ARCTE_HIP_EINVAL, "class index out of range");
+    HIP_TRY(hipSetDevice(f->device));
+    DevBuf<int64_t> yp;
+    DevBuf<int32_t> yi;
+    DevBuf<double> m, class_count, variance, weights;
+    DevBuf<uint32_t> count;
+    int rc = [&]() -> int {
+        HIP_TRY(yp.alloc(f->n_rows + 1));
+        HIP_TRY(yi.alloc(ny));
+        HIP_TRY(m.alloc(n_classes * f->n_cols));
+        HIP_TRY(class_count.alloc(n_classes));
+        HIP_TRY(variance.alloc(n_classes));
+        HIP_TRY(weights.alloc(f->n_cols));
+        HIP_TRY(hipMemcpy(yp.p, y_indptr, (f->n_rows + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+        if (ny) HIP_TRY(hipMemcpy(yi.p, y_indices, ny * sizeof(int32_t), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemset(m.p, 0, m.bytes()));
+        HIP_TRY(hipMemset(class_count.p, 0, class_count.bytes()));
+        int r = column_counts(f, count);        // feature_count = X.sum(axis=0) of the ones pattern (:29)
+        if (r) return r;
+        if (f->n_rows) {
+            int blocks = (int)((f->n_rows + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
+            hipLaunchKernelGGL(k_chi2_observed, dim3(blocks), dim3(BLOCK), 0, 0, f->indptr.p, f->indices.p, yp.p, yi.p, f->n_rows, f->n_cols, m.p,
+                               class_count.p);
+        }
+        const int64_t cells = n_classes * f->n_cols;
+        hipLaunchKernelGGL(k_chi2_statistic, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, 0, class_count.p, count.p, f->n_rows, n_classes,
+                           f->n_cols, m.p);
+        hipLaunchKernelGGL(k_psnr_row_variance, dim3((unsigned)n_classes), dim3(256), 0, 0, m.p, f->n_cols, variance.p);
+        hipLaunchKernelGGL(k_psnr_weights, dim3((unsigned)((f->n_cols + 255) / 256)), dim3(256), 0, 0, m.p, n_classes, f->n_cols, variance.p, weights.p);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipDeviceSynchronize());
+        if (contingency_out) HIP_TRY(hipMemcpy(contingency_out, m.p, cells * sizeof(double), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(weights_out, weights.p, f->n_cols * sizeof(double), hipMemcpyDeviceToHost));
+        return 0;
+    }();
+    yp.release(); yi.release(); m.release(); class_count.release(); variance.release(); weights.release(); count.release();
+    return rc;
+}
+
+int arcte_hip_peak_snr_weights(int device, int64_t n_classes, int64_t n_cols, const double *contingency, double *weights_out)
+{
+    if (n_classes <= 0 || n_cols <= 0 || !contingency || !weights_out) return fail(ARCTE_HIP_EINVAL, "bad argument");
+    HIP_TRY(hipSetDevice(device));
+    DevBuf<double> m, variance, weights;
+    int rc = [&]() -> int {
+        HIP_TRY(m.alloc(n_classes * n_cols));
+        HIP_TRY(variance.alloc(n_classes));
+        HIP_TRY(weights.alloc(n_cols));
+        HIP_TRY(hipMemcpy(m.p, contingency, n_classes * n_cols * sizeof(double), hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_psnr_row_variance, dim3((unsigned)n_classes), dim3(256), 0, 0, m.p, n_cols, variance.p);
+        hipLaunchKernelGGL(k_psnr_weights, dim3((unsigned)((n_cols + 255) / 256)), dim3(256), 0, 0, m.p, n_classes, n_cols, variance.p, weights.p);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpy(weights_out, weights.p, n_cols * sizeof(double), hipMemcpyDeviceToHost));
+        return 0;
+    }();
+    m.release(); variance.release(); weights.release();
+    return rc;
+}
+
 int arcte_hip_stream_bandwidth(int device, int64_t bytes, double *read_gbps, double *copy_gbps)
 {
     if (bytes < (1 << 20) || !read_gbps || !copy_gbps) return fail(ARCTE_HIP_EINVAL, "bad argument");
@@ -1160,6 +1824,23 @@ int arcte_hip_set_float32(arcte_hip_ctx *c, int enable)
 {
     if (!c) return fail(ARCTE_HIP_EINVAL, "ctx is NULL");
     c->float32 = enable ? 1 : 0;
+    return 0;
+}
+
+int arcte_hip_launch_occupancy(arcte_hip_ctx *c, int *workgroups_per_cu)
+{
+    if (!c || !workgroups_per_cu) return fail(ARCTE_HIP_EINVAL, "bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    const uint32_t k = hot_values_per_wave(c, sizeof(double));
+    const size_t lds = (size_t)c->waves_per_block * k * sizeof(double);
+    int per_cu = 0;
+    if (k == 0) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (k_arcte_seeds<0, 0, double, 2, false>), c->waves_per_block * WAVE, 0));
+    else {
+        if (lds > 48 * 1024)
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_arcte_seeds<0, 0, double, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (k_arcte_seeds<0, 0, double, 2, true>), c->waves_per_block * WAVE, lds));
+    }
+    *workgroups_per_cu = per_cu;
     return 0;
 }
 

@@ -368,6 +368,20 @@ struct PushParams {
     unsigned long long *stats;   // [0] pushes [1] edges [2] enqueues [3] support [4] failed seeds [5] candidates
 };
 
+// Registers of one step of the push pipeline: the row data of TILES x 64 edges, and the state gathered for them
+template <typename T, int TILES> struct RowStage {
+    bool a[TILES];
+    int32_t v[TILES];
+    uint32_t hh[TILES];
+    T w[TILES], d[TILES];
+};
+template <typename T, int TILES> struct EntStage {
+    LoT<T> l[TILES];
+    HiT<T> h[TILES];
+    T x[TILES];
+    bool chip[TILES];
+};
+
 // MODE 0: full arcte_worker body (extract).  MODE 1: similarity slice only on the dense vectors the
 // host placed in slot 0 (k_state_from_dense), left there for k_state_to_dense.
 // VAR 0: cumulative PageRank difference (push.py:41-64, similarity.py:149-222) -- ARCTE proper.
@@ -490,60 +504,67 @@ __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
                 nsup += g1;
                 nfirst += g1;
             }
-            for (int64_t base = rb; base < re; base += TILES * WAVE) {
-                // TILES x 64 edges per iteration: every load of the iteration is issued before the first use
-                bool a_[TILES], chip_[TILES];
-                int32_t v_[TILES];
-                uint32_t hh_[TILES];
-                T w_[TILES], d_[TILES], x_[TILES];
-                LoT<T> l_[TILES];
-                HiT<T> h_[TILES];
+            // The row is walked TILES x 64 edges at a time as a three-stage software pipeline: the row data (index,
+            // weight, in_degree, hot rank) of step i+2 and the state gathers of step i+1 are in flight while step i
+            // is added, stored and enqueued.  Legal because the targets of one row are distinct (CSR columns are
+            // unique), so a later step's gathers never read what an earlier step of the SAME push stores; across
+            // pushes program order holds (the next push's gathers are issued after this push's last store).
+            RowStage<T, TILES> Ra, Rb, Rc;
+            EntStage<T, TILES> Ea, Eb;
+            // Every lane issues every load of a step, lanes beyond the row's end at a clamped or dummy address (the
+            // row's last edge, the seed's own state entry: lines that are in cache anyway).  Loads under an
+            // exec-masked branch would leave the number of outstanding loads unknown to the compiler, which then
+            // waits for ALL of them (vmcnt(0)) before the first use and serialises the pipeline.
+            auto load_row = [&](int64_t base, RowStage<T, TILES> &R) {
 #pragma unroll
                 for (int t = 0; t < TILES; t++) {
                     const int64_t k = base + t * WAVE + lane;
-                    a_[t] = k < re;
-                    v_[t] = 0; w_[t] = T(0); d_[t] = T(1); hh_[t] = HOT_NONE;
-                    if (a_[t]) {
-                        v_[t] = g.indices[k]; w_[t] = gv.data[k]; d_[t] = gv.edge_in_degree[k];
-                        if (HOT) hh_[t] = P.edge_hot[k];
-                    }
+                    R.a[t] = k < re;
+                    const int64_t kk = R.a[t] ? k : re - 1;
+                    R.v[t] = g.indices[kk]; R.w[t] = gv.data[kk]; R.d[t] = gv.edge_in_degree[kk];
+                    R.hh[t] = HOT ? (uint32_t)P.edge_hot[kk] : HOT_NONE;
                 }
+            };
+            auto gather = [&](const RowStage<T, TILES> &R, EntStage<T, TILES> &E) {
 #pragma unroll
                 for (int t = 0; t < TILES; t++) {
-                    l_[t] = {T(0), T(0)};
-                    h_[t] = {T(1), 0u};
-                    chip_[t] = false;
-                    x_[t] = T(0);
                     // nodes without a place in the table go to HBM at once, the others after a look at the table
-                    if (a_[t] && !(HOT && hh_[t] < K)) { l_[t] = load_lo(st + v_[t]); h_[t] = load_hi(st + v_[t]); }
+                    const bool cold = R.a[t] && !(HOT && R.hh[t] < K);
+                    const EntryT<T> *e = cold ? st + R.v[t] : st + seed;
+                    E.l[t] = load_lo(e);
+                    E.h[t] = load_hi(e);
+                    E.chip[t] = false;
+                    E.x[t] = T(0);
                 }
                 if (HOT) {
 #pragma unroll
                     for (int t = 0; t < TILES; t++) {
-                        if (a_[t] && hh_[t] < K) {
-                            x_[t] = hot[hh_[t]];
-                            chip_[t] = !is_moved(x_[t]);
-                            if (!chip_[t]) { l_[t] = load_lo(st + v_[t]); h_[t] = load_hi(st + v_[t]); }
+                        if (R.a[t] && R.hh[t] < K) {
+                            E.x[t] = hot[R.hh[t]];
+                            E.chip[t] = !is_moved(E.x[t]);
+                            if (!E.chip[t]) { E.l[t] = load_lo(st + R.v[t]); E.h[t] = load_hi(st + R.v[t]); }
                         }
                     }
                 }
+            };
+            auto process = [&](const RowStage<T, TILES> &R, const EntStage<T, TILES> &E) {
 #pragma unroll
                 for (int t = 0; t < TILES; t++) {
-                    const bool act = a_[t];
-                    const bool chip = HOT && chip_[t];
-                    const int32_t v = v_[t];
-                    const T w = w_[t];
-                    const T dv = d_[t];
-                    const LoT<T> lo = l_[t];
-                    const bool live = chip || h_[t].epoch == epoch;
+                    const bool act = R.a[t];
+                    const bool chip = HOT && E.chip[t];
+                    const int32_t v = R.v[t];
+                    const T w = R.w[t];
+                    const T dv = R.d[t];
+                    const LoT<T> lo = E.l[t];
+                    const bool live = chip || E.h[t].epoch == epoch;
                     const T p = c * w;                                  // push.py:62 / :17 / :38
                     // (an on-chip node is never u itself: u has just moved)
-                    const T r_old = chip ? x_[t] : (live ? ((v != u) ? lo.r : r_self) : T(0));   // a self-loop sees r[u] as just set
-                    const T s_old = chip ? ((VAR == 0) ? x_[t] : T(0)) : (live ? lo.s : T(0));
+                    const T r_old = chip ? E.x[t] : (live ? ((v != u) ? lo.r : r_self) : T(0));   // a self-loop sees r[u] as just set
+                    const T s_old = chip ? ((VAR == 0) ? E.x[t] : T(0)) : (live ? lo.s : T(0));
                     const T r_new = r_old + p;                          // push.py:64
                     const T s_new = (VAR == 0) ? s_old + p : s_old;     // push.py:63 (ARCTE only)
                     if (act) {
-                        if (chip) hot[hh_[t]] = r_new;                  // == s_new for ARCTE; s stays 0 otherwise
+                        if (chip) hot[R.hh[t]] = r_new;                 // == s_new for ARCTE; s stays 0 otherwise
                         else {
                             store_lo(st + v, r_new, s_new);
                             if (!live) store_hi(st + v, dv, epoch);
@@ -569,14 +590,33 @@ __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
                         else {
                             if (enq) {
                                 QEntry e;
-                                e.v = v; e.h = hh_[t]; e.d = (double)dv;
+                                e.v = v; e.h = R.hh[t]; e.d = (double)dv;
                                 q[(tail + lane_below(me)) & qmask] = e;
                             }
                             tail += cnt;
                         }
                     }
                 }
-                if (!ok) break;
+            };
+            constexpr int64_t STEP = TILES * WAVE;
+            if (re - rb > STEP) {
+                load_row(rb, Ra);
+                load_row(rb + STEP, Rb);
+                gather(Ra, Ea);
+                for (int64_t base = rb; base < re; base += STEP) {
+                    // (row data first: the wait for it at the top of the next turn then leaves this turn's gathers
+                    //  in flight instead of draining them)
+                    load_row(base + 2 * STEP, Rc);
+                    gather(Rb, Eb);
+                    process(Ra, Ea);
+                    if (!ok) break;
+                    Ra = Rb; Ea = Eb; Rb = Rc;
+                }
+            } else if (re > rb) {
+                // a row that fits one step (most pushes, a minority of the edges): nothing to overlap
+                load_row(rb, Ra);
+                gather(Ra, Ea);
+                process(Ra, Ea);
             }
             npush++;
             nedges += (unsigned long long)(re - rb);
@@ -832,54 +872,74 @@ __global__ void k_to_float(const double *in, float *out, int64_t n)
     if (i < n) out[i] = (float)in[i];
 }
 
-// ---- result assembly: (row, column) pairs -> 64-bit sort keys -> CSR ---------------------------------------
-// local block: seed k's members become (member << 32) | (col_offset + seed id)
-__global__ __launch_bounds__(BLOCK) void k_keys_local(const int32_t *rows, const int64_t *colptr, const int32_t *seeds,
-                                                      int64_t nseeds, uint32_t col_offset, uint64_t *keys)
+// ---- result assembly: (row, column) pairs -> stable sort by ROW -> CSR ----------------------------------------
+// The pairs are laid out so that inside every row they already stand in ascending column order (base block in
+// CSR order, then the local block seed by seed in ascending seed id); a STABLE radix sort on the row id alone
+// (log2 n bits: three 8-bit passes at n = 1M instead of eight over a 64-bit key) then yields the canonical CSR.
+// local block: members of the seed whose ascending rank is j become pairs (member, col_offset + seed id) at
+// dst_off[j]; seg_of[j] = position of that seed in the run.
+__global__ __launch_bounds__(BLOCK) void k_pairs_local(const int32_t *rows, const int64_t *colptr, const int32_t *seeds,
+                                                       const int32_t *seg_of, const int64_t *dst_off, int64_t nseeds,
+                                                       uint32_t col_offset, uint32_t *key_row, uint32_t *val_col)
 {
     const int lane = threadIdx.x & 63;
-    const int64_t k = (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
-    if (k >= nseeds) return;
+    const int64_t j = (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (j >= nseeds) return;
+    const int64_t k = seg_of[j];
     const int64_t b = colptr[k], e = colptr[k + 1];
-    const uint64_t col = (uint64_t)col_offset + (uint32_t)seeds[k];
-    for (int64_t i = b + lane; i < e; i += WAVE) keys[i] = ((uint64_t)(uint32_t)rows[i] << 32) | col;
+    const uint32_t col = col_offset + (uint32_t)seeds[k];
+    const int64_t o = dst_off[j];
+    for (int64_t i = b + lane; i < e; i += WAVE) {
+        key_row[o + (i - b)] = (uint32_t)rows[i];
+        val_col[o + (i - b)] = col;
+    }
 }
 
-// base block I + pattern(W) (arcte.py:676-679): row i gets its stored columns plus i itself; when the row
-// already stores i (self-loop) the identity entry is dropped here and the host doubles that value instead.
-// Row i writes deg(i) + 1 keys at out_base + indptr[i] + i; a dropped identity entry leaves UINT64_MAX, which
-// sorts to the end and is cut off by the caller.
-__global__ __launch_bounds__(BLOCK) void k_keys_base(const int64_t *indptr, const int32_t *indices, int64_t n, uint64_t *keys)
+// base block I + pattern(W) (arcte.py:676-679): row i gets its stored columns with i itself merged in at its sorted
+// place; when the row already stores i (self-loop) the identity entry is dropped here and the host doubles that
+// value instead.  Row i writes deg(i) + 1 pairs at indptr[i] + i; a dropped identity entry leaves row id `n`,
+// which sorts behind every real row and is cut off by the caller.
+__global__ __launch_bounds__(BLOCK) void k_pairs_base(const int64_t *indptr, const int32_t *indices, int64_t n, uint32_t *key_row,
+                                                      uint32_t *val_col)
 {
     const int lane = threadIdx.x & 63;
     const int64_t i = (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
     if (i >= n) return;
     const int64_t b = indptr[i], e = indptr[i + 1];
-    uint64_t *out = keys + b + i;
+    const int64_t o = b + i;
     bool loop = false;
+    int64_t below = 0;       // stored columns smaller than i (rows are ascending): the identity entry's place
     for (int64_t k = b + lane; k < e; k += WAVE) {
         const int32_t c = indices[k];
         loop |= (c == (int32_t)i);
-        out[k - b] = ((uint64_t)(uint32_t)i << 32) | (uint32_t)c;
+        below += (c < (int32_t)i) ? 1 : 0;
     }
     const bool any_loop = __ballot(loop) != 0;
-    if (lane == 0) out[e - b] = any_loop ? ~0ull : (((uint64_t)(uint32_t)i << 32) | (uint32_t)i);
+    for (int off = 32; off > 0; off >>= 1) below += __shfl_xor((long long)below, off, WAVE);
+    for (int64_t k = b + lane; k < e; k += WAVE) {
+        const int32_t c = indices[k];
+        const int64_t pos = (k - b) + ((!any_loop && c > (int32_t)i) ? 1 : 0);
+        key_row[o + pos] = (uint32_t)i;
+        val_col[o + pos] = (uint32_t)c;
+    }
+    if (lane == 0) {
+        const int64_t pos = any_loop ? (e - b) : below;
+        key_row[o + pos] = any_loop ? (uint32_t)n : (uint32_t)i;
+        val_col[o + pos] = (uint32_t)i;
+    }
 }
 
-// sorted keys -> CSR: indices are the low words, indptr[r] = first position whose row is >= r
-__global__ void k_keys_to_csr(const uint64_t *keys, int64_t nkeys, int64_t n, int32_t *indices, int64_t *indptr)
+// sorted row ids -> indptr[r] = first position whose row is >= r, for r in [0, n]
+__global__ void k_rows_to_indptr_u32(const uint32_t *rows, int64_t nkeys, int64_t n, int64_t *indptr)
 {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < nkeys) indices[t] = (int32_t)(uint32_t)keys[t];
-    if (t <= n) {
-        const uint64_t target = (uint64_t)t << 32;
-        int64_t lo = 0, hi = nkeys;
-        while (lo < hi) {
-            const int64_t mid = (lo + hi) >> 1;
-            if (keys[mid] < target) lo = mid + 1; else hi = mid;
-        }
-        indptr[t] = lo;
+    if (t > n) return;
+    int64_t lo = 0, hi = nkeys;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (rows[mid] < (uint32_t)t) lo = mid + 1; else hi = mid;
     }
+    indptr[t] = lo;
 }
 
 // work-order keys: seeds with a big row first (their first push and their threshold pass walk the whole row)

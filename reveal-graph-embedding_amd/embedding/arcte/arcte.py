@@ -9,7 +9,6 @@ import numpy as np
 import scipy.sparse as sparse
 
 from reveal_graph_embedding_amd import _native
-from reveal_graph_embedding_amd.eps_randomwalk.transition import get_natural_random_walk_matrix
 
 
 def parallel_chunks(l, n):
@@ -61,49 +60,59 @@ def _seed_matrix(n, seeds, colptr, rows):
     return sparse.csr_matrix(features)
 
 
-def _finish_base_values(features, rw_transition):
+def _set_self_loop_values(features, loop_nodes):
     """The device-assembled pattern stores ONE diagonal entry for a node with a self-loop; the reference's
-    identity + ones (arcte.py:676-679) makes that value 2.0.  (The host-assembled fallback already has it.)"""
-    if rw_transition is None:
-        return features
-    n = rw_transition.shape[0]
-    row_of = np.repeat(np.arange(n), np.diff(rw_transition.indptr))
-    for i in row_of[rw_transition.indices == row_of]:
+    identity + ones (arcte.py:676-679) makes that value 2.0."""
+    for i in loop_nodes:
         lo, hi = features.indptr[i], features.indptr[i + 1]
         features.data[lo + np.searchsorted(features.indices[lo:hi], i)] = 2.0
     return features
 
 
-def _worker(variant, iterate_nodes, indices_c, indptr_c, data_c, out_degree, in_degree, rho, epsilon, device,
-            with_base_block=False):
+def _finish_base_values(features, rw_transition):
+    """(host-assembled matrices already carry the 2.0 of I + ones)"""
+    if rw_transition is None:
+        return features
+    n = rw_transition.shape[0]
+    row_of = np.repeat(np.arange(n), np.diff(rw_transition.indptr))
+    return _set_self_loop_values(features, row_of[rw_transition.indices == row_of])
+
+
+def _features_of_run(ctx, variant, iterate_nodes, rho, epsilon, with_base_block, pattern):
+    """Run `iterate_nodes` on the context and return the reference's matrix: n x n local communities
+    (arcte.py:379-388) or, with the base block, arcte()'s n x 2n [I + pattern | local] (arcte.py:676-683).
+    `pattern()` supplies the n x n pattern of ones for the host-assembly fallback only."""
     iterate_nodes = np.asarray(iterate_nodes, dtype=np.int64).reshape(-1)
-    number_of_nodes = out_degree.size
+    number_of_nodes = ctx.n
     laziness_factor = 0.5
     if variant == _native.LAZY_PAGERANK:
         rho = (rho*(0.5))/(1-(0.5*rho))          # lazy_rho, reference arcte.py:109
-    with _native.Context(indptr_c, indices_c, data_c, out_degree, in_degree, device=device) as ctx:
-        ctx.run_seeds(iterate_nodes, rho, epsilon, use_effective_epsilon=True, variant=variant,
-                      laziness_factor=laziness_factor)
-        if with_base_block or np.unique(iterate_nodes).size == iterate_nodes.size:
-            # the device sorts the (row, seed) pairs into the CSR the reference builds via COO (arcte.py:379-388)
-            try:
-                indptr, indices = ctx.fetch_csr(with_base_block)
-            except _native.ArcteHipError as e:
-                if e.code != -3:                      # ARCTE_HIP_ECAPACITY: too many entries for the 32-bit key sort
-                    raise
-            else:
-                width = 2 * number_of_nodes if with_base_block else number_of_nodes
-                index_dtype = np.int32 if max(width, indices.size) < 2 ** 31 else np.int64
-                return sparse.csr_matrix((np.ones(indices.size, dtype=np.float64), indices,
-                                          indptr.astype(index_dtype)), shape=(number_of_nodes, width))
-        colptr, rows = ctx.fetch()
+    ctx.run_seeds(iterate_nodes, rho, epsilon, use_effective_epsilon=True, variant=variant,
+                  laziness_factor=laziness_factor)
+    if with_base_block or np.unique(iterate_nodes).size == iterate_nodes.size:
+        # the device sorts the (row, seed) pairs into the CSR the reference builds via COO (arcte.py:379-388)
+        try:
+            indptr, indices = ctx.fetch_csr(with_base_block)
+        except _native.ArcteHipError as e:
+            if e.code != -3:                      # ARCTE_HIP_ECAPACITY: too many entries for the device assembly
+                raise
+        else:
+            width = 2 * number_of_nodes if with_base_block else number_of_nodes
+            index_dtype = np.int32 if max(width, indices.size) < 2 ** 31 else np.int64
+            return sparse.csr_matrix((np.ones(indices.size, dtype=np.float64), indices.astype(index_dtype, copy=False),
+                                      indptr.astype(index_dtype)), shape=(number_of_nodes, width))
+    colptr, rows = ctx.fetch()
     local = _seed_matrix(number_of_nodes, iterate_nodes, colptr, rows)
     if not with_base_block:
         return local
-    pattern = sparse.csr_matrix((np.ones(len(data_c), dtype=np.float64), indices_c, indptr_c),
-                                shape=(number_of_nodes, number_of_nodes))
-    base = sparse.csr_matrix(sparse.eye(number_of_nodes, number_of_nodes, dtype=np.float64)) + pattern
+    base = sparse.csr_matrix(sparse.eye(number_of_nodes, number_of_nodes, dtype=np.float64)) + pattern()
     return _finish_base_values(sparse.hstack([base, local]).tocsr(), None)
+
+
+def _worker(variant, iterate_nodes, indices_c, indptr_c, data_c, out_degree, in_degree, rho, epsilon, device):
+    number_of_nodes = out_degree.size
+    with _native.Context(indptr_c, indices_c, data_c, out_degree, in_degree, device=device) as ctx:
+        return _features_of_run(ctx, variant, iterate_nodes, rho, epsilon, False, None)
 
 
 def arcte_worker(iterate_nodes, indices_c, indptr_c, data_c, out_degree, in_degree, rho, epsilon, device=0):
@@ -174,7 +183,7 @@ def arcte(adjacency_matrix, rho, epsilon, number_of_threads=None):
 
 
 def _arcte_driver(adjacency_matrix, rho, epsilon, number_of_threads, worker):
-    adjacency_matrix = sparse.csr_matrix(adjacency_matrix)
+    adjacency_matrix = sparse.csr_matrix(adjacency_matrix, dtype=np.float64)
     number_of_nodes = adjacency_matrix.shape[0]
 
     n_gpus = _native.device_count()
@@ -187,52 +196,61 @@ def _arcte_driver(adjacency_matrix, rho, epsilon, number_of_threads, worker):
     if number_of_threads is not None:
         devices = devices[:max(1, int(number_of_threads))]
     n_gpus = len(devices)
+    variant = _VARIANT_OF[worker]
 
-    rw_transition, out_degree, in_degree = get_natural_random_walk_matrix(adjacency_matrix)
-    iterate_nodes = seed_nodes(adjacency_matrix)
+    def pattern():
+        ones = adjacency_matrix.copy()
+        ones.data = np.ones_like(ones.data, dtype=np.float64)
+        return ones
 
-    variant = _VARIANT_OF.get(worker)
-    if n_gpus == 1 and variant is not None and rw_transition.nnz + number_of_nodes * 1100 < 2 ** 31:
-        # One GPU: the whole n x 2n pattern [I + pattern(A) | local communities] (arcte.py:676-683) is assembled on
-        # the device; the only values that are not 1 are the diagonal entries of nodes with a self-loop (I + ones).
-        features = _worker(variant, np.sort(iterate_nodes), rw_transition.indices, rw_transition.indptr,
-                           rw_transition.data, out_degree, in_degree, rho, epsilon, devices[0], with_base_block=True)
-        return _finish_base_values(features, rw_transition)
-    if n_gpus == 1 or iterate_nodes.size < 2:
-        # the library orders the work heaviest-first by itself; ascending ids make the result a CSC matrix
-        local_features = worker(np.sort(iterate_nodes), rw_transition.indices, rw_transition.indptr, rw_transition.data,
-                                out_degree, in_degree, rho, epsilon)
-    else:
-        chunks = [None if c is None else np.sort(c) for c in parallel_chunks(iterate_nodes, n_gpus)]
-        results = [None] * n_gpus
-        errors = []
+    def self_loops():
+        row_of = np.repeat(np.arange(number_of_nodes), np.diff(adjacency_matrix.indptr))
+        return row_of[adjacency_matrix.indices == row_of]
 
-        def work(k):
-            try:
-                if chunks[k] is not None:
-                    results[k] = worker(chunks[k], rw_transition.indices, rw_transition.indptr,
-                                        rw_transition.data, out_degree, in_degree, rho, epsilon, device=devices[k])
-            except BaseException as e:  # surfaced below; the reference drops worker errors silently
-                errors.append(e)
+    # The adjacency matrix goes to the GPU as it is: the transition matrix, both degree vectors and the seed list
+    # (arcte.py:608-617) are made there (arcte_hip_create_from_adjacency) and never come back.
+    if n_gpus == 1:
+        with _native.Context.from_adjacency(adjacency_matrix.indptr, adjacency_matrix.indices, adjacency_matrix.data,
+                                            device=devices[0]) as ctx:
+            # the library orders the work heaviest-first by itself; ascending ids make the result a CSC matrix.
+            # The whole n x 2n pattern [I + pattern(A) | local communities] (arcte.py:676-683) is assembled on the
+            # device; the only values that are not 1 are the diagonal entries of nodes with a self-loop (I + ones).
+            features = _features_of_run(ctx, variant, np.sort(ctx.seed_list()), rho, epsilon, True, pattern)
+        return _set_self_loop_values(features, self_loops())
 
-        threads = [threading.Thread(target=work, args=(k,)) for k in range(n_gpus)]
-        for t in threads:
-            t.start()
-        for t in threads:
-            t.join()
-        if errors:
-            raise errors[0]
-        results = [x for x in results if x is not None]
+    results = [None] * n_gpus
+    errors = []
+
+    def work(k):
+        try:
+            with _native.Context.from_adjacency(adjacency_matrix.indptr, adjacency_matrix.indices, adjacency_matrix.data,
+                                                device=devices[k]) as ctx:
+                chunk = roundrobin_chunks(ctx.seed_list(), n_gpus, k)          # arcte.py:650-651
+                if chunk is not None:
+                    results[k] = _features_of_run(ctx, variant, np.sort(np.asarray(chunk, dtype=np.int64)), rho, epsilon,
+                                                  False, None)
+        except BaseException as e:  # surfaced below; the reference drops worker errors silently
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(n_gpus)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if errors:
+        raise errors[0]
+    results = [x for x in results if x is not None]
+    if results:
         local_features = results[0]
         for additive_features in results[1:]:
             local_features = local_features + additive_features
         local_features = sparse.csr_matrix(local_features)
+    else:
+        local_features = sparse.csr_matrix((number_of_nodes, number_of_nodes), dtype=np.float64)
 
     # Form base community feature matrix (arcte.py:676-679).
     identity_matrix = sparse.csr_matrix(sparse.eye(number_of_nodes, number_of_nodes, dtype=np.float64))
-    adjacency_matrix_ones = adjacency_matrix.copy()
-    adjacency_matrix_ones.data = np.ones_like(adjacency_matrix_ones.data, dtype=np.float64)
-    base_community_features = identity_matrix + adjacency_matrix_ones
+    base_community_features = identity_matrix + pattern()
 
     # Stack horizontally matrices to form feature matrix (arcte.py:683).
     features = sparse.hstack([base_community_features, local_features]).tocsr()

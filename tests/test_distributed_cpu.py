@@ -31,8 +31,12 @@ def _worker(rank, world, port, name, out_path):
     from reveal_graph_embedding_amd.distributed import arcte_distributed
     g = load_golden(name)
 
-    def run_shard(w, od, idg, seeds, rho, eps):
-        return oracle.worker(w, od, idg, seeds, rho, eps)
+    def run_shard(adjacency, rank_, world_, rho, eps):
+        from reveal_graph_embedding_amd.distributed import shard_seeds
+        w, od, idg = oracle.get_natural_random_walk_matrix(adjacency)
+        seeds = oracle.seed_list(adjacency)
+        colptr, rows = oracle.worker(w, od, idg, shard_seeds(seeds, world_, rank_), rho, eps)
+        return seeds, colptr, rows
 
     f = arcte_distributed(g["adjacency"], g["rho"], g["epsilon"], run_shard=run_shard)
     if rank == 0:

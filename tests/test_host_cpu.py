@@ -10,7 +10,6 @@ import scipy.sparse as sparse
 from conftest import ROOT, assert_same_sparse
 
 from reveal_graph_embedding_amd import _native
-from reveal_graph_embedding_amd.eps_randomwalk.transition import get_natural_random_walk_matrix
 from reveal_graph_embedding_amd.embedding.arcte.arcte import parallel_chunks, roundrobin_chunks, seed_nodes
 from reveal_graph_embedding_amd.synthetic import rmat_graph
 
@@ -59,22 +58,6 @@ def test_product_does_not_import_oracle():
                 text = open(os.path.join(base, f)).read()
                 for needle in ("import oracle", "from oracle", "liboracle", "oracle/", "oracle."):
                     assert needle not in text, (needle, os.path.join(base, f))
-
-
-def test_transition_matrix_matches_reference_fixture(golden):
-    w, out_degree, in_degree = get_natural_random_walk_matrix(golden["adjacency"])
-    assert_same_sparse(w, golden["w"])
-    assert np.array_equal(out_degree, golden["out_degree"])
-    assert np.array_equal(in_degree, golden["in_degree"])
-    assert w.has_sorted_indices
-
-
-def test_transition_zero_out_degree_rows_and_unsorted_input():
-    a = sparse.coo_matrix((np.array([2.0, 1.0, 4.0]), (np.array([0, 0, 2]), np.array([2, 1, 0]))), shape=(3, 3))
-    w, od, idg = get_natural_random_walk_matrix(a)
-    assert np.array_equal(od, [3.0, 1.0, 4.0])
-    assert np.array_equal(idg, [4.0, 1.0, 2.0])
-    assert np.array_equal(w.toarray(), [[0, 1 / 3.0, 2 / 3.0], [0, 0, 0], [1.0, 0, 0]])
 
 
 def test_chunkers_match_reference_semantics():

@@ -1,25 +1,69 @@
-import sys, time, numpy as np
-sys.path.insert(0, ".")
-from reveal_graph_embedding_amd.synthetic import rmat_graph
-from reveal_graph_embedding_amd.embedding.arcte import arcte as A
-from reveal_graph_embedding_amd.eps_randomwalk.transition import get_natural_random_walk_matrix
-from reveal_graph_embedding_amd import _native
-n, m = int(sys.argv[1]), int(sys.argv[2])
-adj = rmat_graph(n, m, 0)
-for it in range(2):
-    t0 = time.time(); f = A.arcte(adj, 0.1, 1e-5, 1); t1 = time.time()
-    print("arcte() end-to-end %.3f s, nnz %d" % (t1 - t0, f.nnz), flush=True)
-if n > 200000:
-    sys.exit(0)
-t = time.time(); w, od, idg = get_natural_random_walk_matrix(adj); print(" a1 transition %.3f" % (time.time() - t))
-t = time.time(); seeds = A.seed_nodes(adj); print(" seed list %.3f" % (time.time() - t))
-t = time.time(); ctx = _native.Context(w.indptr, w.indices, w.data, od, idg); print(" context (upload+slots) %.3f" % (time.time() - t))
-t = time.time(); ctx.run_seeds(seeds, 0.1, 1e-5); print(" run_seeds %.3f" % (time.time() - t))
-t = time.time(); colptr, rows = ctx.fetch(); print(" fetch D2H %.3f (%d rows)" % (time.time() - t, rows.size))
-t = time.time(); ctx.close(); print(" close %.3f" % (time.time() - t))
-t = time.time(); loc = A._seed_matrix(n, seeds, colptr, rows); print(" seed matrix (coo->csr) %.3f" % (time.time() - t))
+"""End-to-end arcte() on the R-MAT graph with a breakdown of where the wall-clock time goes.
+
+usage: python tools/e2e_time.py NODES EDGES
+"""
+import mmap
+import os
+import sys
+import time
+
+import numpy as np
 import scipy.sparse as sparse
-t = time.time()
-identity = sparse.csr_matrix(sparse.eye(n, n, dtype=np.float64)); ones = adj.copy(); ones.data = np.ones_like(ones.data); base = identity + ones
-print(" base block %.3f" % (time.time() - t))
-t = time.time(); f = sparse.hstack([base, loc]).tocsr(); print(" hstack %.3f" % (time.time() - t))
+
+sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from reveal_graph_embedding_amd import _native
+from reveal_graph_embedding_amd.embedding.arcte import arcte as A
+from hot_sweep import load_graph
+
+
+def main():
+    n, m = int(sys.argv[1]), int(sys.argv[2])
+    adj = load_graph(n, m)
+    for it in range(2):
+        t0 = time.time()
+        f = A.arcte(adj, 0.1, 1e-5, 1)
+        print("arcte() end-to-end %.3f s, nnz %d" % (time.time() - t0, f.nnz), flush=True)
+        del f
+    t = time.time()
+    ctx = _native.Context.from_adjacency(adj.indptr, adj.indices, adj.data)
+    print(" context from adjacency (H2D, transition + seed list on the device, slots) %.3f" % (time.time() - t), flush=True)
+    t = time.time()
+    seeds = np.sort(ctx.seed_list())
+    print(" seed list D2H + sort %.3f (%d seeds)" % (time.time() - t, seeds.size), flush=True)
+    t = time.time()
+    ctx.run_seeds(seeds, 0.1, 1e-5)
+    tm = ctx.timing()
+    print(" run_seeds %.3f (push kernel %.3f)" % (time.time() - t, tm["push_ms"] / 1e3), flush=True)
+    t = time.time()
+    indptr, indices = ctx.fetch_csr(True)
+    print(" device assembly + D2H of %d column ids %.3f" % (indices.size, time.time() - t), flush=True)
+    t = time.time()
+    ones = np.ones(indices.size)
+    print(" np.ones(nnz) %.3f" % (time.time() - t), flush=True)
+    del ones
+    t = time.time()
+    mm = mmap.mmap(-1, indices.size * 8, flags=mmap.MAP_PRIVATE | mmap.MAP_ANONYMOUS)
+    mm.madvise(mmap.MADV_HUGEPAGE)
+    ones = np.frombuffer(mm, dtype=np.float64)
+    ones.fill(1.0)
+    print(" huge-page-advised ones %.3f" % (time.time() - t), flush=True)
+    t = time.time()
+    f = sparse.csr_matrix((ones, indices, indptr.astype(np.int32 if indices.size < 2 ** 31 else np.int64)), shape=(n, 2 * n))
+    print(" csr_matrix constructor %.3f" % (time.time() - t), flush=True)
+    t = time.time()
+    ctx.close()
+    print(" close %.3f" % (time.time() - t), flush=True)
+    # cross-check: the host-assembly path must give the same matrix
+    if n <= 200000:
+        os.environ["ARCTE_HIP_MAX_SORT_KEYS"] = "1000"
+        g = A.arcte(adj, 0.1, 1e-5, 1)
+        del os.environ["ARCTE_HIP_MAX_SORT_KEYS"]
+        g.sort_indices()
+        f = A.arcte(adj, 0.1, 1e-5, 1)
+        print(" device assembly == host assembly:", np.array_equal(f.indptr, g.indptr) and np.array_equal(f.indices, g.indices)
+              and np.array_equal(f.data, g.data), flush=True)
+
+
+if __name__ == "__main__":
+    main()
