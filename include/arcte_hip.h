@@ -134,6 +134,24 @@ int arcte_hip_run_seeds_variant(arcte_hip_ctx *ctx, const int64_t *seeds, int64_
                                 double rho, double epsilon, int use_effective_epsilon,
                                 int variant, double laziness_factor);
 
+/*
+ * The loop of arcte_and_centrality (embedding/arcte/cython_opt/arcte.pyx:165-217), the reference's older
+ * single-process driver, for the nodes in [node_begin, node_end): every node WITH out-edges is a seed, in index order;
+ * the propagation runs with the RAW epsilon; s/in_degree of every support node is added to a centrality vector in
+ * seed order (per node a left fold, exactly the reference's sequence of additions: the contributions of a batch of
+ * seeds are sorted by (node, seed) on the device and folded by one thread per node); the community is everything at
+ * or above the smallest value inside the closed neighbourhood, emitted iff it has more members than that
+ * neighbourhood (a set: a self-loop does not count twice).  Where a node outside the neighbourhood TIES with that
+ * smallest value the reference's own answer depends on numpy's unstable argsort (arcte.pyx:194-208); this takes it.
+ * Nodes of the range without out-edges get centrality 1.0 (arcte.pyx:210).  Results: arcte_hip_fetch_result (one
+ * entry per seed of the range, in order), arcte_hip_fetch_centrality, arcte_hip_features_from_result (columns
+ * numbered by a running counter over the emitting seeds, arcte.pyx:213-215; base block = identity + W, see there).
+ * A sub-range gives the partial sums of that range (one rank of a sharded run: add the vectors, then concatenate).
+ */
+int arcte_hip_run_centrality(arcte_hip_ctx *ctx, int64_t node_begin, int64_t node_end, double rho, double epsilon);
+/* centrality[n] of the last arcte_hip_run_centrality. */
+int arcte_hip_fetch_centrality(arcte_hip_ctx *ctx, double *centrality);
+
 /* Sizes of the last run: number of seeds and total emitted (row, seed) pairs. */
 int arcte_hip_result_sizes(arcte_hip_ctx *ctx, int64_t *nseeds, int64_t *total_rows);
 

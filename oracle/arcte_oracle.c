@@ -504,10 +504,12 @@ int64_t oracle_push_trace(int64_t n, const int64_t *indptr, const int32_t *indic
  *
  * colptr[n+1] / *rows_out: community of seed i = rows[colptr[i] .. colptr[i+1]) (ascending ids; empty when nothing
  * is emitted).  centrality[n] is overwritten.  Returns 0, -1 on allocation failure.
+ * node_begin / node_end restrict the seeds (and the 1.0 of non-seeds) to a block of nodes: the partial result of one
+ * rank of a sharded run; colptr then has node_end - node_begin + 1 entries.
  */
 int oracle_arcte_and_centrality(int64_t n, const int64_t *indptr, const int32_t *indices, const double *data,
-                                const double *in_degree, double rho, double epsilon, int64_t *colptr,
-                                int32_t **rows_out, double *centrality)
+                                const double *in_degree, double rho, double epsilon, int64_t node_begin, int64_t node_end,
+                                int64_t *colptr, int32_t **rows_out, double *centrality)
 {
     double *s = (double *)calloc((size_t)n, sizeof(double));
     double *r = (double *)calloc((size_t)n, sizeof(double));
@@ -518,7 +520,8 @@ int oracle_arcte_and_centrality(int64_t n, const int64_t *indptr, const int32_t 
     if (!s || !r || !touched) rc = -1;
     for (int64_t i = 0; i < n; i++) centrality[i] = 0.0;
     colptr[0] = 0;
-    for (int64_t seed = 0; seed < n && !rc; seed++) {
+    colptr -= node_begin;                                       /* colptr[seed] for seed in [node_begin, node_end] */
+    for (int64_t seed = node_begin; seed < node_end && !rc; seed++) {
         colptr[seed + 1] = colptr[seed];
         const int64_t b = indptr[seed], e = indptr[seed + 1];
         if (e == b) continue;                                   /* arcte.pyx:165: out_degree != 0 */
@@ -558,7 +561,7 @@ int oracle_arcte_and_centrality(int64_t n, const int64_t *indptr, const int32_t 
         /* back to zero: s is non-zero exactly on the touched list; r only where s is (every deposit adds to both) */
         for (int64_t t = 0; t < ntouched; t++) { s[touched[t]] = 0.0; r[touched[t]] = 0.0; }
     }
-    for (int64_t i = 0; i < n && !rc; i++)
+    for (int64_t i = node_begin; i < node_end && !rc; i++)
         if (indptr[i + 1] == indptr[i]) centrality[i] = 1.0;    /* arcte.pyx:210 */
     free(s); free(r); free(touched); free(q.buf);
     if (rc) { free(out.buf); *rows_out = 0; return rc; }

@@ -62,8 +62,8 @@ def lib():
         l.oracle_push_variant.restype = None
         l.oracle_push_variant.argtypes = [C.c_int, C.c_double] + l.oracle_push.argtypes
         l.oracle_arcte_and_centrality.restype = C.c_int
-        l.oracle_arcte_and_centrality.argtypes = [C.c_int64, _i64p, _i32p, _f64p, _f64p, C.c_double, C.c_double, _i64p,
-                                                  C.POINTER(C.POINTER(C.c_int32)), _f64p]
+        l.oracle_arcte_and_centrality.argtypes = [C.c_int64, _i64p, _i32p, _f64p, _f64p, C.c_double, C.c_double, C.c_int64,
+                                                  C.c_int64, _i64p, C.POINTER(C.POINTER(C.c_int32)), _f64p]
         l.oracle_free.restype = None
         l.oracle_free.argtypes = [C.c_void_p]
         l.oracle_max_threads.restype = C.c_int
@@ -245,22 +245,33 @@ def normalize_community_features(features):
     return normalize_rows(normalize_columns(features))
 
 
-def arcte_and_centrality(adjacency_matrix, rho, epsilon):
-    """arcte.pyx:125-241.  Returns (features n x (n + emitted communities) CSR, centrality[n])."""
+def centrality_block(adjacency_matrix, rho, epsilon, node_begin=0, node_end=None):
+    """The seed loop of arcte.pyx:165-217 for the nodes in [node_begin, node_end): (colptr, rows, partial centrality)."""
     a = sparse.csr_matrix(adjacency_matrix, dtype=np.float64)
     n = a.shape[0]
+    node_end = n if node_end is None else int(node_end)
     w, out_degree, in_degree = get_natural_random_walk_matrix(a)
     indptr, indices, data = _csr_arrays(w)
-    colptr = np.zeros(n + 1, dtype=np.int64)
+    colptr = np.zeros(node_end - node_begin + 1, dtype=np.int64)
     rows_p = C.POINTER(C.c_int32)()
     centrality = np.zeros(n, dtype=np.float64)
     rc = lib().oracle_arcte_and_centrality(n, indptr, indices, data, np.ascontiguousarray(in_degree, dtype=np.float64),
-                                           float(rho), float(epsilon), colptr, C.byref(rows_p), centrality)
+                                           float(rho), float(epsilon), int(node_begin), node_end, colptr, C.byref(rows_p),
+                                           centrality)
     if rc != 0:
         raise RuntimeError("oracle_arcte_and_centrality failed with status %d" % rc)
     total = int(colptr[-1])
     rows = np.ctypeslib.as_array(rows_p, shape=(max(total, 1),))[:total].copy()
     lib().oracle_free(rows_p)
+    return colptr, rows, centrality
+
+
+def arcte_and_centrality(adjacency_matrix, rho, epsilon):
+    """arcte.pyx:125-241.  Returns (features n x (n + emitted communities) CSR, centrality[n])."""
+    a = sparse.csr_matrix(adjacency_matrix, dtype=np.float64)
+    n = a.shape[0]
+    w, out_degree, in_degree = get_natural_random_walk_matrix(a)
+    colptr, rows, centrality = centrality_block(a, rho, epsilon)
     sizes = np.diff(colptr)
     emitted = np.flatnonzero(sizes)
     cols = np.repeat(np.arange(emitted.size), sizes[emitted])                      # arcte.pyx:213-215: running counter

@@ -35,6 +35,8 @@ SIGNATURES = {
     "arcte_hip_run_seeds": (C.c_int, [C.c_void_p, _i64p, C.c_int64, C.c_double, C.c_double, C.c_int]),
     "arcte_hip_run_seeds_variant": (C.c_int, [C.c_void_p, _i64p, C.c_int64, C.c_double, C.c_double, C.c_int, C.c_int,
                                               C.c_double]),
+    "arcte_hip_run_centrality": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_double, C.c_double]),
+    "arcte_hip_fetch_centrality": (C.c_int, [C.c_void_p, _f64p]),
     "arcte_hip_result_sizes": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "arcte_hip_fetch_result": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "arcte_hip_result_csr_size": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int64)]),
@@ -228,6 +230,16 @@ class Context:
         _check(lib().arcte_hip_run_seeds_variant(self._h, seeds, seeds.size, float(rho), float(epsilon),
                                                  1 if use_effective_epsilon else 0, int(variant),
                                                  float(laziness_factor)))
+
+    def run_centrality(self, rho, epsilon, node_begin=0, node_end=None):
+        """The loop of arcte_and_centrality (arcte.pyx:165-217) for the nodes in [node_begin, node_end)."""
+        _check(lib().arcte_hip_run_centrality(self._h, int(node_begin), int(self.n if node_end is None else node_end),
+                                              float(rho), float(epsilon)))
+
+    def centrality(self):
+        out = np.zeros(self.n, dtype=np.float64)
+        _check(lib().arcte_hip_fetch_centrality(self._h, out))
+        return out
 
     def result_sizes(self):
         ns, tot = C.c_int64(0), C.c_int64(0)

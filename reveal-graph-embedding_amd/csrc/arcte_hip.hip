@@ -98,15 +98,6 @@ int32_t max_pushes_limit()
     return 1 << 26;
 }
 
-int32_t refresh_policy()
-{
-    // "failing" (default): after a push only the batch entries that did not pass are re-read, a passing entry is
-    // re-read when its turn comes.  "all": every unconsumed entry is re-read after every push.  Both are exact;
-    // A/B on one MI355X: 126.4 vs 127.9 ms per bench launch.
-    const char *env = getenv("ARCTE_HIP_REFRESH");
-    return (env && !strcmp(env, "all")) ? 0 : 1;
-}
-
 uint32_t next_pow2(uint64_t x);
 // The FIFO holds a few hundred entries for typical seeds; an overflowing seed is re-run with a 4x ring.
 uint32_t default_queue_capacity(int64_t n);
@@ -147,6 +138,10 @@ struct arcte_hip_ctx {
     // hot table (LDS-resident state of the highest-degree nodes) and the launch shape that goes with it
     DevBuf<uint16_t> node_hot, edge_hot;
     int64_t hot_ranked = 0;      // nodes that carry a rank (<= HOT_NONE)
+    // arcte_and_centrality (arcte.pyx:125-241)
+    DevBuf<uint64_t> contrib_key;
+    DevBuf<double> contrib_val, centrality;
+    int centrality_run = 0;      // the last run was arcte_hip_run_centrality: columns are numbered by a running counter
     DevBuf<int32_t> ranked_ids;  // every node by descending pattern in-count, ties by node id (stable)
     int64_t nseeds_all = 0;      // arcte.py:617: how many of them have an in-count above 1 = the seed list
     int waves_per_block = 1;     // wavefronts per workgroup of k_arcte_seeds
@@ -259,6 +254,7 @@ uint32_t hot_values_per_wave(const arcte_hip_ctx *c, size_t value_bytes)
     const size_t reserve = (size_t)std::max(0, env_int("ARCTE_HIP_LDS_RESERVE_KB", 8)) * 1024;
     size_t per_wave = (LDS_PER_CU - std::min(reserve, LDS_PER_CU / 2)) / (size_t)c->waves_per_cu;
     per_wave = per_wave / 1024 * 1024;
+    per_wave -= std::min(per_wave, WATCH_SLOTS * (sizeof(int32_t) + value_bytes));     // the watch table sits behind the hot table
     uint64_t k = per_wave / value_bytes;
     k = std::min<uint64_t>(k, (uint64_t)c->hot_ranked);
     if (cap > 0) k = std::min<uint64_t>(k, (uint64_t)cap);
@@ -282,16 +278,30 @@ int launch_seeds_v(arcte_hip_ctx *c, PushParams P, int64_t nwork)
     P.hotK = 0;
     if (MODE == 1) {
         // works on the dense vectors the host placed in slot 0: exactly one wavefront may run, all state in HBM
-        return launch_with_lds(k_arcte_seeds<MODE, VAR, T, 2, false>, 1, WAVE, 0, c->stream, P);
+        return launch_with_lds(k_arcte_seeds<MODE, VAR, T, 2, false>, 1, WAVE, watch_bytes<T>(), c->stream, P);
     }
     const int wpb = c->waves_per_block;
     const int64_t waves = std::min<int64_t>(c->slots, std::max<int64_t>(nwork, 1));
     const int blocks = (int)((waves + wpb - 1) / wpb);
     P.hotK = hot_values_per_wave(c, sizeof(T));
-    const size_t lds = (size_t)wpb * P.hotK * sizeof(T);
-    if (P.hotK == 0) return launch_with_lds(k_arcte_seeds<MODE, VAR, T, 2, false>, blocks, wpb * WAVE, 0, c->stream, P);
+    const size_t lds = (size_t)wpb * (P.hotK * sizeof(T) + watch_bytes<T>());
+    if (P.hotK == 0) return launch_with_lds(k_arcte_seeds<MODE, VAR, T, 2, false>, blocks, wpb * WAVE, lds, c->stream, P);
     if (c->tiles == 4) return launch_with_lds(k_arcte_seeds<MODE, VAR, T, 4, true>, blocks, wpb * WAVE, lds, c->stream, P);
     return launch_with_lds(k_arcte_seeds<MODE, VAR, T, 2, true>, blocks, wpb * WAVE, lds, c->stream, P);
+}
+
+// MODE 2 exists for ARCTE's own push in float64 only (arcte.pyx has no other flavour)
+int launch_centrality(arcte_hip_ctx *c, PushParams P, int64_t nwork)
+{
+    P.edge_hot = c->edge_hot.p;
+    P.node_hot = c->node_hot.p;
+    const int wpb = c->waves_per_block;
+    const int64_t waves = std::min<int64_t>(c->slots, std::max<int64_t>(nwork, 1));
+    const int blocks = (int)((waves + wpb - 1) / wpb);
+    P.hotK = hot_values_per_wave(c, sizeof(double));
+    const size_t lds = (size_t)wpb * (P.hotK * sizeof(double) + watch_bytes<double>());
+    if (P.hotK == 0) return launch_with_lds(k_arcte_seeds<2, 0, double, 2, false>, blocks, wpb * WAVE, lds, c->stream, P);
+    return launch_with_lds(k_arcte_seeds<2, 0, double, 2, true>, blocks, wpb * WAVE, lds, c->stream, P);
 }
 
 template <int MODE, typename T>
@@ -360,7 +370,7 @@ int ctx_begin(int device, int64_t n, int64_t nnz, arcte_hip_ctx **out)
         HIP_TRY(c->data.alloc(nnz));
         HIP_TRY(c->out_degree.alloc(n));
         HIP_TRY(c->in_degree.alloc(n));
-        HIP_TRY(c->counters.alloc(8));
+        HIP_TRY(c->counters.alloc(16));
         return 0;
     }();
     if (rc) {
@@ -796,7 +806,7 @@ int arcte_hip_destroy(arcte_hip_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     c->indptr.release(); c->indices.release(); c->data.release(); c->out_degree.release(); c->in_degree.release();
-    c->state.release(); c->slot_epoch.release(); c->ranked_ids.release(); c->node_hot.release(); c->edge_hot.release(); c->edge_in_degree.release(); c->data_f.release(); c->in_degree_f.release(); c->edge_in_degree_f.release(); c->queue.release(); c->sup.release();
+    c->state.release(); c->slot_epoch.release(); c->contrib_key.release(); c->contrib_val.release(); c->centrality.release(); c->ranked_ids.release(); c->node_hot.release(); c->edge_hot.release(); c->edge_in_degree.release(); c->data_f.release(); c->in_degree_f.release(); c->edge_in_degree_f.release(); c->queue.release(); c->sup.release();
     c->seeds_d.release(); c->work_pos.release(); c->out_cnt.release(); c->status.release(); c->nop_d.release();
     c->eps_d.release(); c->out_off.release(); c->dst_off.release(); c->counters.release();
     c->raw.release(); c->rows_final.release(); c->sort_keys.release(); c->sort_iota.release(); c->sort_temp.release(); c->eps_big_pos.release(); c->sort_keys_in.release();
@@ -856,8 +866,13 @@ int arcte_hip_epsilon_effective(arcte_hip_ctx *c, const int64_t *seeds, int64_t 
     return 0;
 }
 
+// mode 0: arcte_worker's loop.  mode 2: the loop of arcte_and_centrality (the caller has reset the contribution
+// cursor counters[8]); returns RC_RETRY_BATCH (> 0, nothing of the batch may be used) when a seed has to be re-run --
+// its contributions could otherwise be counted twice -- after growing whatever was too small.
+constexpr int RC_RETRY_BATCH = 1, RC_CONTRIB_FULL = 2;
+
 static int run_seeds_impl(arcte_hip_ctx *c, const int64_t *seeds, int64_t nseeds, double rho, double epsilon,
-                          int use_effective_epsilon, int variant, double lazy)
+                          int use_effective_epsilon, int variant, double lazy, int mode = 0)
 {
     if (!c || nseeds < 0 || (nseeds && !seeds)) return fail(ARCTE_HIP_EINVAL, "bad argument");
     if (variant < 0 || variant > 2) return fail(ARCTE_HIP_EINVAL, "variant must be 0 (ARCTE), 1 (PageRank) or 2 (lazy PageRank)");
@@ -865,6 +880,8 @@ static int run_seeds_impl(arcte_hip_ctx *c, const int64_t *seeds, int64_t nseeds
     HIP_TRY(hipSetDevice(c->device));
     auto t0 = std::chrono::steady_clock::now();
     c->run_nseeds = -1;
+    c->centrality_run = 0;
+    if (mode == 2 && (variant != 0 || c->float32)) return fail(ARCTE_HIP_EINVAL, "the centrality driver runs ARCTE's own push in float64");
     {
         int rp = prepare_precision(c);
         if (rp) return rp;
@@ -979,7 +996,7 @@ static int run_seeds_impl(arcte_hip_ctx *c, const int64_t *seeds, int64_t nseeds
         const int64_t nwork = (int64_t)work.size();
         if (!identity && !(sorted_on_device && launches == 0))
             HIP_TRY(hipMemcpyAsync(c->work_pos.p, work.data(), nwork * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipMemsetAsync(c->counters.p, 0, 8 * sizeof(unsigned long long), c->stream));
+        HIP_TRY(hipMemsetAsync(c->counters.p, 0, 8 * sizeof(unsigned long long), c->stream));     // (the contribution cursor [8] runs on)
         PushParams P;
         P.g = c->graph();
         P.work_pos = identity ? nullptr : c->work_pos.p;
@@ -996,7 +1013,8 @@ static int run_seeds_impl(arcte_hip_ctx *c, const int64_t *seeds, int64_t nseeds
         P.sup = c->sup.p;
         P.qcap = c->qcap;
         P.max_pushes = max_pushes_limit();
-        P.refresh_failing_only = refresh_policy();
+        P.prefetch_next = env_int("ARCTE_HIP_PREFETCH", 1) ? 1 : 0;
+        P.watch = env_int("ARCTE_HIP_WATCH", 1) ? 1 : 0;
         P.raw = c->raw.p;
         P.rawcap = c->raw.count;
         P.raw_cursor = c->counters.p + 1;
@@ -1005,8 +1023,12 @@ static int run_seeds_impl(arcte_hip_ctx *c, const int64_t *seeds, int64_t nseeds
         P.status = c->status.p;
         P.nop = c->nop_d.p;
         P.stats = c->counters.p + 2;
+        P.contrib_key = c->contrib_key.p;
+        P.contrib_val = c->contrib_val.p;
+        P.contrib_cap = c->contrib_key.count;
+        P.contrib_cursor = c->counters.p + 8;
         HIP_TRY(hipEventRecord(c->ev[2], c->stream));
-        r = launch_seeds<0>(c, P, nwork, variant);
+        r = (mode == 2) ? launch_centrality(c, P, nwork) : launch_seeds<0>(c, P, nwork, variant);
         if (r) return r;
         HIP_TRY(hipEventRecord(c->ev[3], c->stream));
         launches++;
@@ -1023,7 +1045,7 @@ static int run_seeds_impl(arcte_hip_ctx *c, const int64_t *seeds, int64_t nseeds
 
         // finished seeds of this launch: their rows are appended to rows_final in caller (position) order
         next.clear();
-        bool queue_over = false, out_over = false;
+        bool queue_over = false, out_over = false, contrib_over = false;
         int64_t add = 0;
         std::vector<int32_t> by_pos(work);
         std::sort(by_pos.begin(), by_pos.end());
@@ -1043,8 +1065,22 @@ static int run_seeds_impl(arcte_hip_ctx *c, const int64_t *seeds, int64_t nseeds
             } else {
                 queue_over |= (st == ST_QUEUE_OVERFLOW);
                 out_over |= (st == ST_OUTPUT_OVERFLOW);
+                contrib_over |= (st == ST_CONTRIB_OVERFLOW);
                 next.push_back(pos);
             }
+        }
+        if (mode == 2 && !next.empty()) {
+            if (contrib_over) return RC_CONTRIB_FULL;
+            if (queue_over) {
+                r = grow_queue(c);
+                if (r) return r;
+            }
+            if (out_over) {
+                if (c->raw.count >= ((size_t)1 << 33)) return fail(ARCTE_HIP_ECAPACITY, "the output arena cannot grow further");
+                size_t want = c->raw.count * 4;
+                HIP_TRY(c->raw.alloc(want));
+            }
+            return RC_RETRY_BATCH;
         }
         if (add > 0) {
             if ((size_t)(final_used + add) > c->rows_final.count) {
@@ -1131,6 +1167,131 @@ int arcte_hip_run_seeds_variant(arcte_hip_ctx *c, const int64_t *seeds, int64_t 
     return run_seeds_impl(c, seeds, nseeds, rho, epsilon, use_effective_epsilon, variant, laziness_factor);
 }
 
+int arcte_hip_run_centrality(arcte_hip_ctx *c, int64_t node_begin, int64_t node_end, double rho, double epsilon)
+{
+    if (!c || node_begin < 0 || node_end > c->n || node_begin > node_end) return fail(ARCTE_HIP_EINVAL, "bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    c->run_nseeds = -1;
+    std::vector<int64_t> seeds;                                        // arcte.pyx:165: nodes with out-edges, in index order
+    for (int64_t i = node_begin; i < node_end; i++)
+        if (c->row_len[(size_t)i] > 0) seeds.push_back(i);
+    const int64_t ns = (int64_t)seeds.size();
+    HIP_TRY(c->centrality.alloc(c->n));
+    HIP_TRY(hipMemsetAsync(c->centrality.p, 0, c->centrality.bytes(), c->stream));
+    // contribution arena of one batch: (node << 32 | seed, value) pairs, sorted and folded per batch
+    if (!c->contrib_key.p) {
+        size_t free_b = 0, total_b = 0;
+        HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+        size_t cap = std::min<size_t>((size_t)1 << 29, free_b / 8 / 16);
+        if (const char *env = getenv("ARCTE_HIP_CONTRIB_ENTRIES")) {   // test hook: force small batches
+            long long v = atoll(env);
+            if (v > 0) cap = (size_t)v;
+        }
+        cap = std::max<size_t>(cap, (size_t)c->n);
+        HIP_TRY(c->contrib_key.alloc(cap));
+        HIP_TRY(c->contrib_val.alloc(cap));
+    }
+    DevBuf<int32_t> all_rows;
+    DevBuf<uint64_t> key_sorted;
+    DevBuf<double> val_sorted;
+    DevBuf<char> temp;
+    std::vector<int64_t> all_colptr((size_t)ns + 1, 0);
+    int64_t stats_sum[6] = {0, 0, 0, 0, 0, 0}, cand_sum = 0, rows_used = 0;
+    double ms_sum[4] = {0, 0, 0, 0};
+    auto t0 = std::chrono::steady_clock::now();
+    int rc = [&]() -> int {
+        int key_bits = 33;
+        while (key_bits < 64 && ((uint64_t)1 << (key_bits - 32)) < (uint64_t)c->n) key_bits++;
+        double per_seed = (double)std::min<int64_t>(c->n, 4096);
+        int64_t pos = 0;
+        while (pos < ns) {
+            int64_t batch = std::max<int64_t>(1, std::min<int64_t>(ns - pos, (int64_t)((double)c->contrib_key.count / per_seed)));
+            unsigned long long m = 0;
+            for (;;) {
+                HIP_TRY(hipMemsetAsync(c->counters.p + 8, 0, sizeof(unsigned long long), c->stream));
+                int r = run_seeds_impl(c, seeds.data() + pos, batch, rho, epsilon, 0, 0, 0.0, 2);
+                if (r < 0) return r;
+                if (r == RC_CONTRIB_FULL) {
+                    if (batch == 1) {
+                        size_t want = c->contrib_key.count * 2;
+                        HIP_TRY(c->contrib_key.alloc(want));
+                        HIP_TRY(c->contrib_val.alloc(want));
+                    } else batch = std::max<int64_t>(1, batch / 2);
+                    continue;
+                }
+                if (r == RC_RETRY_BATCH) continue;
+                break;
+            }
+            HIP_TRY(hipMemcpy(&m, c->counters.p + 8, sizeof(m), hipMemcpyDeviceToHost));
+            if (m) {
+                HIP_TRY(key_sorted.reserve(m));
+                HIP_TRY(val_sorted.reserve(m));
+                size_t tb = 0;
+                HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, c->contrib_key.p, key_sorted.p, c->contrib_val.p, val_sorted.p, (size_t)m, 0,
+                                                           key_bits, c->stream));
+                HIP_TRY(temp.reserve(tb));
+                HIP_TRY(hipcub::DeviceRadixSort::SortPairs(temp.p, tb, c->contrib_key.p, key_sorted.p, c->contrib_val.p, val_sorted.p, (size_t)m, 0,
+                                                           key_bits, c->stream));
+                hipLaunchKernelGGL(k_apply_contributions, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream, key_sorted.p, val_sorted.p,
+                                   (int64_t)m, c->centrality.p);
+                HIP_TRY(hipGetLastError());
+            }
+            // this batch's communities behind the earlier ones
+            if (c->final_rows) {
+                if ((size_t)(rows_used + c->final_rows) > all_rows.count) {
+                    DevBuf<int32_t> bigger;
+                    HIP_TRY(bigger.alloc(std::max<size_t>((size_t)(rows_used + c->final_rows), all_rows.count * 2)));
+                    if (rows_used) HIP_TRY(hipMemcpyAsync(bigger.p, all_rows.p, rows_used * sizeof(int32_t), hipMemcpyDeviceToDevice, c->stream));
+                    HIP_TRY(hipStreamSynchronize(c->stream));
+                    all_rows.release();
+                    all_rows = bigger;
+                    bigger.p = nullptr;
+                }
+                HIP_TRY(hipMemcpyAsync(all_rows.p + rows_used, c->rows_final.p, c->final_rows * sizeof(int32_t), hipMemcpyDeviceToDevice, c->stream));
+            }
+            for (int64_t k = 0; k < batch; k++) all_colptr[(size_t)(pos + k) + 1] = rows_used + c->colptr[(size_t)k + 1];
+            rows_used += c->final_rows;
+            for (int i = 0; i < 6; i++) stats_sum[i] += c->stats[i];
+            cand_sum += c->candidates;
+            for (int i = 0; i < 3; i++) ms_sum[i] += c->ms[i];
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            per_seed = std::max(64.0, 1.25 * (double)m / (double)batch);
+            pos += batch;
+        }
+        if (node_end > node_begin)
+            hipLaunchKernelGGL(k_centrality_non_seeds, dim3((unsigned)((node_end - node_begin + 255) / 256)), dim3(256), 0, c->stream,
+                               c->indptr.p + node_begin, node_end - node_begin, c->centrality.p + node_begin);
+        HIP_TRY(hipGetLastError());
+        int r = upload_seeds(c, seeds.data(), ns);
+        if (r) return r;
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        return 0;
+    }();
+    key_sorted.release(); val_sorted.release(); temp.release();
+    if (rc) { all_rows.release(); c->run_nseeds = -1; return rc; }
+    c->rows_final.release();
+    c->rows_final = all_rows;
+    all_rows.p = nullptr;
+    c->final_rows = rows_used;
+    c->colptr.swap(all_colptr);
+    for (int i = 0; i < 6; i++) c->stats[i] = stats_sum[i];
+    c->candidates = cand_sum;
+    for (int i = 0; i < 3; i++) c->ms[i] = ms_sum[i];
+    c->ms[3] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    c->run_nseeds = ns;
+    c->centrality_run = 1;
+    return 0;
+}
+
+int arcte_hip_fetch_centrality(arcte_hip_ctx *c, double *centrality)
+{
+    if (!c || !centrality) return fail(ARCTE_HIP_EINVAL, "bad argument");
+    if (c->run_nseeds < 0 || !c->centrality_run) return fail(ARCTE_HIP_ESTATE, "no completed centrality run on this context");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpy(centrality, c->centrality.p, c->n * sizeof(double), hipMemcpyDeviceToHost));
+    return 0;
+}
+
 int arcte_hip_result_sizes(arcte_hip_ctx *c, int64_t *nseeds, int64_t *total_rows)
 {
     if (!c) return fail(ARCTE_HIP_EINVAL, "ctx is NULL");
@@ -1167,7 +1328,10 @@ int arcte_hip_result_csr_size(arcte_hip_ctx *c, int with_base_block, int64_t *nn
 }
 
 // The last run as CSR on the device: indptr_d[n+1], cols (uint32 column ids, the first *valid of them).
-static int assemble_csr_device(arcte_hip_ctx *c, int with_base_block, DevBuf<int64_t> &indptr_d, DevBuf<uint32_t> &cols, int64_t *valid_out)
+// Columns: seed id (arcte(): every seed owns its column) or, after arcte_hip_run_centrality, a running counter over the
+// seeds that emitted a community (arcte.pyx:213-215); *n_local_cols receives the width of the local block.
+static int assemble_csr_device(arcte_hip_ctx *c, int with_base_block, DevBuf<int64_t> &indptr_d, DevBuf<uint32_t> &cols, int64_t *valid_out,
+                               int64_t *n_local_cols = nullptr)
 {
     if (c->run_nseeds < 0) return fail(ARCTE_HIP_ESTATE, "no completed run on this context");
     HIP_TRY(hipSetDevice(c->device));
@@ -1197,9 +1361,23 @@ static int assemble_csr_device(arcte_hip_ctx *c, int with_base_block, DevBuf<int
     }
     DevBuf<uint32_t> key_a, key_b, val_a;
     DevBuf<int64_t> colptr_d, dst_d;
-    DevBuf<int32_t> seg_d;
+    DevBuf<int32_t> seg_d, colid_d;
     DevBuf<char> temp;
+    std::vector<int32_t> colid_h;
+    int64_t local_cols = n;
+    if (c->centrality_run) {
+        colid_h.assign((size_t)std::max<int64_t>(ns, 1), 0);
+        int32_t next_col = 0;
+        for (int64_t k = 0; k < ns; k++)
+            if (c->colptr[(size_t)k + 1] > c->colptr[(size_t)k]) colid_h[(size_t)k] = next_col++;
+        local_cols = next_col;
+    }
+    if (n_local_cols) *n_local_cols = local_cols;
     int rc = [&]() -> int {
+        if (c->centrality_run) {
+            HIP_TRY(colid_d.alloc(ns));
+            if (ns) HIP_TRY(hipMemcpyAsync(colid_d.p, colid_h.data(), ns * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+        }
         HIP_TRY(key_a.alloc(nkeys));
         HIP_TRY(key_b.alloc(nkeys));
         HIP_TRY(val_a.alloc(nkeys));
@@ -1219,8 +1397,9 @@ static int assemble_csr_device(arcte_hip_ctx *c, int with_base_block, DevBuf<int
         }
         if (ns && c->final_rows) {
             int blocks = (int)((ns + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
-            hipLaunchKernelGGL(k_pairs_local, dim3(blocks), dim3(BLOCK), 0, c->stream, c->rows_final.p, colptr_d.p, c->seeds_d.p, seg_d.p,
-                               dst_d.p, ns, with_base_block ? (uint32_t)n : 0u, key_a.p, val_a.p);
+            hipLaunchKernelGGL(k_pairs_local, dim3(blocks), dim3(BLOCK), 0, c->stream, c->rows_final.p, colptr_d.p,
+                               c->centrality_run ? colid_d.p : c->seeds_d.p, seg_d.p, dst_d.p, ns, with_base_block ? (uint32_t)n : 0u, key_a.p,
+                               val_a.p);
         }
         HIP_TRY(hipGetLastError());
         int end_bit = 1;                      // row ids 0 .. n (n = dropped identity entries, sorted to the end)
@@ -1238,7 +1417,7 @@ static int assemble_csr_device(arcte_hip_ctx *c, int with_base_block, DevBuf<int
         *valid_out = valid;
         return 0;
     }();
-    key_a.release(); key_b.release(); val_a.release(); colptr_d.release(); dst_d.release(); seg_d.release(); temp.release();
+    key_a.release(); key_b.release(); val_a.release(); colptr_d.release(); dst_d.release(); seg_d.release(); colid_d.release(); temp.release();
     return rc;
 }
 
@@ -1358,12 +1537,13 @@ static int similarity_slice_impl(arcte_hip_ctx *c, int64_t seed, double rho, dou
             P.rho = rho;
             P.lazy = lazy;
             P.state = (void *)c->state.p;
-        P.slot_epoch = c->slot_epoch.p;
+            P.slot_epoch = c->slot_epoch.p;
             P.queue = c->queue.p;
             P.sup = c->sup.p;
             P.qcap = c->qcap;
             P.max_pushes = max_pushes_limit();
-            P.refresh_failing_only = refresh_policy();
+            P.prefetch_next = env_int("ARCTE_HIP_PREFETCH", 1) ? 1 : 0;
+        P.watch = env_int("ARCTE_HIP_WATCH", 1) ? 1 : 0;
             P.raw = nullptr;
             P.rawcap = 0;
             P.raw_cursor = c->counters.p + 1;
@@ -1537,6 +1717,32 @@ __global__ __launch_bounds__(BLOCK) void k_feat_values_of_result(const int64_t *
         if (indices[k] == (int32_t)i) data[k] = 2.0;
 }
 
+// arcte_and_centrality's matrix (arcte.pyx:219-228): local communities hold ones; the base block is identity + the
+// matrix the reference holds under the name adjacency_matrix at that point -- which is W (cython_opt/transition.pyx:19
+// normalises its argument in place), so entry (i, c) = W[i, c] + (1 if c == i)
+__global__ __launch_bounds__(BLOCK) void k_feat_values_identity_plus_w(const int64_t *w_indptr, const int32_t *w_indices, const double *w_data,
+                                                                       const int64_t *indptr, const int32_t *indices, int64_t n, double *data)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const int64_t wb = w_indptr[i], we = w_indptr[i + 1];
+    for (int64_t k = indptr[i] + lane; k < indptr[i + 1]; k += WAVE) {
+        const int32_t col = indices[k];
+        double v = 1.0;
+        if ((int64_t)col < n) {
+            int64_t lo = wb, hi = we;
+            while (lo < hi) {
+                const int64_t mid = (lo + hi) >> 1;
+                if (w_indices[mid] < col) lo = mid + 1; else hi = mid;
+            }
+            const double w = (lo < we && w_indices[lo] == col) ? w_data[lo] : 0.0;
+            v = (col == (int32_t)i) ? 1.0 + w : w;
+        }
+        data[k] = v;
+    }
+}
+
 int arcte_hip_features_from_result(arcte_hip_ctx *c, int with_base_block, arcte_hip_features **out)
 {
     if (!c || !out) return fail(ARCTE_HIP_EINVAL, "bad argument");
@@ -1544,17 +1750,22 @@ int arcte_hip_features_from_result(arcte_hip_ctx *c, int with_base_block, arcte_
     DevBuf<int64_t> indptr_d;
     DevBuf<uint32_t> cols;
     int64_t valid = 0;
-    int rc = assemble_csr_device(c, with_base_block, indptr_d, cols, &valid);
+    int64_t local_cols = 0;
+    int rc = assemble_csr_device(c, with_base_block, indptr_d, cols, &valid, &local_cols);
     if (rc) { indptr_d.release(); cols.release(); return rc; }
     arcte_hip_features *f = new arcte_hip_features();
-    f->device = c->device; f->n_rows = c->n; f->n_cols = with_base_block ? 2 * c->n : c->n; f->nnz = valid;
+    f->device = c->device; f->n_rows = c->n; f->n_cols = (with_base_block ? c->n : 0) + local_cols; f->nnz = valid;
     f->indptr = indptr_d; indptr_d.p = nullptr;
     f->indices.p = reinterpret_cast<int32_t *>(cols.p); f->indices.count = (size_t)valid; f->indices.capacity = cols.capacity; cols.p = nullptr;
     rc = [&]() -> int {
         HIP_TRY(f->data.alloc(valid));
         int blocks = (int)((c->n + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
-        hipLaunchKernelGGL(k_feat_values_of_result, dim3(blocks), dim3(BLOCK), 0, c->stream, c->indptr.p, c->indices.p, f->indptr.p, f->indices.p,
-                           c->n, with_base_block, f->data.p);
+        if (c->centrality_run && with_base_block)
+            hipLaunchKernelGGL(k_feat_values_identity_plus_w, dim3(blocks), dim3(BLOCK), 0, c->stream, c->indptr.p, c->indices.p, c->data.p,
+                               f->indptr.p, f->indices.p, c->n, f->data.p);
+        else
+            hipLaunchKernelGGL(k_feat_values_of_result, dim3(blocks), dim3(BLOCK), 0, c->stream, c->indptr.p, c->indices.p, f->indptr.p, f->indices.p,
+                               c->n, with_base_block, f->data.p);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(c->stream));
         return 0;
@@ -1832,9 +2043,9 @@ int arcte_hip_launch_occupancy(arcte_hip_ctx *c, int *workgroups_per_cu)
     if (!c || !workgroups_per_cu) return fail(ARCTE_HIP_EINVAL, "bad argument");
     HIP_TRY(hipSetDevice(c->device));
     const uint32_t k = hot_values_per_wave(c, sizeof(double));
-    const size_t lds = (size_t)c->waves_per_block * k * sizeof(double);
+    const size_t lds = (size_t)c->waves_per_block * (k * sizeof(double) + watch_bytes<double>());
     int per_cu = 0;
-    if (k == 0) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (k_arcte_seeds<0, 0, double, 2, false>), c->waves_per_block * WAVE, 0));
+    if (k == 0) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (k_arcte_seeds<0, 0, double, 2, false>), c->waves_per_block * WAVE, lds));
     else {
         if (lds > 48 * 1024)
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_arcte_seeds<0, 0, double, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

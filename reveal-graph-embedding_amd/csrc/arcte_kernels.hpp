@@ -22,6 +22,7 @@ enum SeedStatus : int32_t {
     ST_OUTPUT_OVERFLOW = 2,
     ST_MISSING_BASE = 3,
     ST_RUNAWAY = 4,   // push cap hit: every wave must reach an exit (guards against a non-converging input)
+    ST_CONTRIB_OVERFLOW = 5,   // MODE 2: the centrality contributions of this batch do not fit their arena
 };
 
 __device__ __forceinline__ int lane_below(uint64_t m)
@@ -333,6 +334,15 @@ template <> __device__ __forceinline__ float hot_moved<float>() { return __uint_
 __device__ __forceinline__ bool is_moved(double x) { return __double_as_longlong(x) == 0x7FF8DEAD0000BEEFll; }
 __device__ __forceinline__ bool is_moved(float x) { return __float_as_uint(x) == 0x7FC0BEEFu; }
 
+// Watch table (LDS, per wavefront): the nodes of the pop batch in flight and their CURRENT r.  Every deposit of a
+// push looks its target up here and, on a hit, leaves the new r; the re-test of the not yet consumed batch entries
+// after a push (similarity.py:204 needs r at pop time) then reads LDS instead of gathering from HBM again -- one
+// dependent memory round trip less per push.  256 slots for at most 64 nodes: open addressing, linear probing.
+constexpr int WATCH_SLOTS = 256;
+constexpr uint32_t WATCH_NONE = 0xFFFFFFFFu;
+template <typename T> constexpr size_t watch_bytes() { return WATCH_SLOTS * (sizeof(int32_t) + sizeof(T)); }
+__device__ __forceinline__ uint32_t watch_hash(int32_t v) { return ((uint32_t)v * 2654435761u) >> 24; }
+
 struct PushParams {
     GraphDev g;
     // hot table (LDS): nodes ranked by pattern in-degree; edge_hot[k] = rank of indices[k] (HOT_NONE beyond the
@@ -356,7 +366,8 @@ struct PushParams {
     int32_t *sup;      // [slots][n]   candidate list (see cand_thr)
     uint32_t qcap;     // power of two
     int32_t max_pushes; // per-seed cap, see ST_RUNAWAY
-    int32_t refresh_failing_only;   // pop-batch refresh policy (both exact)
+    int32_t prefetch_next;   // fetch the next passing entry's row data while the current one is pushed
+    int32_t watch;           // keep the pop batch's r values current in LDS (0: re-read them from HBM after every push)
     // outputs
     int32_t *raw;      // raw row arena, allocation order
     unsigned long long rawcap;
@@ -366,7 +377,33 @@ struct PushParams {
     int32_t *status;
     int32_t *nop;
     unsigned long long *stats;   // [0] pushes [1] edges [2] enqueues [3] support [4] failed seeds [5] candidates
+    // MODE 2: (node << 32 | seed, s/in_degree) of every support node of every seed, for the centrality accumulation
+    uint64_t *contrib_key;
+    double *contrib_val;
+    unsigned long long contrib_cap;
+    unsigned long long *contrib_cursor;
 };
+
+// arcte.pyx:190-191: centrality += s_norm, seed after seed.  The contributions of a batch of seeds, sorted by
+// (node, seed): one thread per node folds its run into centrality[node] in ascending seed order -- per node exactly
+// the reference's sequence of additions.
+__global__ void k_apply_contributions(const uint64_t *keys, const double *vals, int64_t m, double *centrality)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= m) return;
+    const uint32_t v = (uint32_t)(keys[k] >> 32);
+    if (k != 0 && (uint32_t)(keys[k - 1] >> 32) == v) return;
+    double acc = centrality[v];
+    for (int64_t j = k; j < m && (uint32_t)(keys[j] >> 32) == v; j++) acc += vals[j];
+    centrality[v] = acc;
+}
+
+// arcte.pyx:210: nodes that were no seeds (no out-edges) get centrality 1
+__global__ void k_centrality_non_seeds(const int64_t *indptr, int64_t n, double *centrality)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && indptr[i + 1] == indptr[i]) centrality[i] = 1.0;
+}
 
 // Registers of one step of the push pipeline: the row data of TILES x 64 edges, and the state gathered for them
 template <typename T, int TILES> struct RowStage {
@@ -383,7 +420,8 @@ template <typename T, int TILES> struct EntStage {
 };
 
 // MODE 0: full arcte_worker body (extract).  MODE 1: similarity slice only on the dense vectors the
-// host placed in slot 0 (k_state_from_dense), left there for k_state_to_dense.
+// host placed in slot 0 (k_state_from_dense), left there for k_state_to_dense.  MODE 2: the body of
+// arcte_and_centrality (embedding/arcte/cython_opt/arcte.pyx:168-217): MODE 0 plus the centrality contributions.
 // VAR 0: cumulative PageRank difference (push.py:41-64, similarity.py:149-222) -- ARCTE proper.
 // VAR 1: PageRank limit push (push.py:4-17, similarity.py:11-63).
 // VAR 2: lazy PageRank push (push.py:20-38, similarity.py:66-146) with its self re-push loops.
@@ -409,7 +447,10 @@ __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
     const uint32_t qmask = P.qcap - 1;
     const T omr = (T)P.one_minus_rho;
     const uint32_t K = HOT ? P.hotK : 0u;
-    T *hot = reinterpret_cast<T *>(hot_raw) + (size_t)wave * K;
+    unsigned char *lds_wave = hot_raw + (size_t)wave * ((size_t)K * sizeof(T) + watch_bytes<T>());
+    T *hot = reinterpret_cast<T *>(lds_wave);
+    int32_t *wkey = reinterpret_cast<int32_t *>(lds_wave + (size_t)K * sizeof(T));
+    T *wval = reinterpret_cast<T *>(lds_wave + (size_t)K * sizeof(T) + WATCH_SLOTS * sizeof(int32_t));
     uint32_t epoch = P.slot_epoch[slot];
 
     // Dynamic seed queue: lane 0 draws the next work item, the wave broadcasts it.  The
@@ -438,7 +479,7 @@ __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
         const int32_t pos = P.work_pos ? P.work_pos[wk] : (int32_t)wk;
         const int32_t seed = P.seeds[pos];
         const T eps = (T)P.eps[pos];
-        if (MODE == 0) {
+        if (MODE != 1) {
             // the arena is already full: this seed is re-run by the host after the arena is drained
             unsigned long long cur = 0;
             if (lane == 0) cur = __hip_atomic_load(P.raw_cursor, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -459,6 +500,7 @@ __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
             // s[:] = 0; r[:] = 0 for the on-chip nodes
             for (uint32_t i = lane; i < K; i += WAVE) hot[i] = T(0);
         }
+        for (int i = lane; i < WATCH_SLOTS; i += WAVE) wkey[i] = -1;       // no batch in flight yet
 
         uint32_t head = 0, tail = 0;       // ring counters (wave-uniform)
         int32_t nsup = 0;          // candidates
@@ -468,9 +510,27 @@ __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
         unsigned long long nedges = 0;
         bool ok = true, runaway = false;
 
+        // row data of one pipeline step: TILES x 64 edges from `base`, clamped to the row's last edge `re - 1`.
+        // Every lane issues every load of a step, lanes beyond the row's end at a clamped or dummy address (the
+        // row's last edge, the seed's own state entry: lines that are in cache anyway).  Loads under an
+        // exec-masked branch would leave the number of outstanding loads unknown to the compiler, which then
+        // waits for ALL of them (vmcnt(0)) before the first use and serialises the pipeline.
+        auto load_row_at = [&](int64_t base, int64_t re, RowStage<T, TILES> &R) {
+#pragma unroll
+            for (int t = 0; t < TILES; t++) {
+                const int64_t k = base + t * WAVE + lane;
+                R.a[t] = k < re;
+                const int64_t kk = R.a[t] ? k : re - 1;
+                R.v[t] = g.indices[kk]; R.w[t] = gv.data[kk]; R.d[t] = gv.edge_in_degree[kk];
+                R.hh[t] = HOT ? (uint32_t)P.edge_hot[kk] : HOT_NONE;
+            }
+        };
+
         // ---- one push of node u (push.py:41-64) followed by the ordered enqueue of
         //      similarity.py:194-196 / :214-216.  `ru` is r[u] at pop time, `hu` u's hot rank, `du` its in_degree.
-        auto push = [&](int32_t u, uint32_t hu, T du, T ru, int64_t rb, int64_t re, bool do_enqueue) {
+        //      `pre`: the row data of the first step when the pop loop has fetched it ahead (NULL otherwise).
+        auto push = [&](int32_t u, uint32_t hu, uint32_t wu, T du, T ru, int64_t rb, int64_t re, bool do_enqueue,
+                        const RowStage<T, TILES> *pre) {
             T c;            // what every neighbour receives per unit of transition weight
             T r_self;       // r[u] right after the push bookkeeping (what a self-loop lane adds to)
             // u still on chip: this push is its first, so s[u] == r[u] == ru (ARCTE) or s[u] == 0 (PageRank
@@ -504,6 +564,7 @@ __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
                 nsup += g1;
                 nfirst += g1;
             }
+            if (wu != WATCH_NONE && lane == 0) wval[wu] = r_self;   // r[u] as the batch sees it from now on
             // The row is walked TILES x 64 edges at a time as a three-stage software pipeline: the row data (index,
             // weight, in_degree, hot rank) of step i+2 and the state gathers of step i+1 are in flight while step i
             // is added, stored and enqueued.  Legal because the targets of one row are distinct (CSR columns are
@@ -511,20 +572,7 @@ __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
             // pushes program order holds (the next push's gathers are issued after this push's last store).
             RowStage<T, TILES> Ra, Rb, Rc;
             EntStage<T, TILES> Ea, Eb;
-            // Every lane issues every load of a step, lanes beyond the row's end at a clamped or dummy address (the
-            // row's last edge, the seed's own state entry: lines that are in cache anyway).  Loads under an
-            // exec-masked branch would leave the number of outstanding loads unknown to the compiler, which then
-            // waits for ALL of them (vmcnt(0)) before the first use and serialises the pipeline.
-            auto load_row = [&](int64_t base, RowStage<T, TILES> &R) {
-#pragma unroll
-                for (int t = 0; t < TILES; t++) {
-                    const int64_t k = base + t * WAVE + lane;
-                    R.a[t] = k < re;
-                    const int64_t kk = R.a[t] ? k : re - 1;
-                    R.v[t] = g.indices[kk]; R.w[t] = gv.data[kk]; R.d[t] = gv.edge_in_degree[kk];
-                    R.hh[t] = HOT ? (uint32_t)P.edge_hot[kk] : HOT_NONE;
-                }
-            };
+            auto load_row = [&](int64_t base, RowStage<T, TILES> &R) { load_row_at(base, re, R); };
             auto gather = [&](const RowStage<T, TILES> &R, EntStage<T, TILES> &E) {
 #pragma unroll
                 for (int t = 0; t < TILES; t++) {
@@ -569,6 +617,12 @@ __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
                             store_lo(st + v, r_new, s_new);
                             if (!live) store_hi(st + v, dv, epoch);
                         }
+                        // is v waiting in the pop batch?  then its r there is this one now
+                        if (P.watch) for (uint32_t ws = watch_hash(v);; ws = (ws + 1) & (WATCH_SLOTS - 1)) {
+                            const int32_t wk = wkey[ws];
+                            if (wk == v) { wval[ws] = r_new; break; }
+                            if (wk == -1) break;
+                        }
                     }
                     if (VAR == 0) {
                         // Candidate list: every node whose s/in_degree has reached cand_thr, a lower bound of
@@ -600,7 +654,7 @@ __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
             };
             constexpr int64_t STEP = TILES * WAVE;
             if (re - rb > STEP) {
-                load_row(rb, Ra);
+                if (pre) Ra = *pre; else load_row(rb, Ra);
                 load_row(rb + STEP, Rb);
                 gather(Ra, Ea);
                 for (int64_t base = rb; base < re; base += STEP) {
@@ -614,7 +668,7 @@ __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
                 }
             } else if (re > rb) {
                 // a row that fits one step (most pushes, a minority of the edges): nothing to overlap
-                load_row(rb, Ra);
+                if (pre) Ra = *pre; else load_row(rb, Ra);
                 gather(Ra, Ea);
                 process(Ra, Ea);
             }
@@ -628,9 +682,9 @@ __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
         const T seed_d = gv.in_degree[seed];
         if (lane == 0) {
             if (VAR == 0) store_lo(st + seed, T(1), T(1));         // similarity.py:176-177
-            else if (MODE == 0) store_lo(st + seed, T(1), T(0));   // similarity.py:26 / :85: only r[seed] = 1
+            else if (MODE != 1) store_lo(st + seed, T(1), T(0));   // similarity.py:26 / :85: only r[seed] = 1
             else st[seed].r = T(1);                                //   (MODE 1: the caller's s[seed] stays)
-            if (MODE == 0) store_hi(st + seed, seed_d, epoch);   // MODE 1: the host made every entry live
+            if (MODE != 1) store_hi(st + seed, seed_d, epoch);   // MODE 1: the host made every entry live
             if (VAR == 0) sup[0] = seed;
             if (HOT) {
                 const uint32_t hs = P.node_hot[seed];
@@ -653,13 +707,13 @@ __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
             cand_thr = wave_min_real<T>(lb) * cand_margin<T>();
         }
         // (PageRank flavours: s is non-zero only at pushed nodes; the candidate list is the pushed nodes)
-        push(seed, HOT_NONE, seed_d, T(1), seed_b, seed_e, true);
+        push(seed, HOT_NONE, WATCH_NONE, seed_d, T(1), seed_b, seed_e, true, nullptr);
         if (VAR == 2) {
             // similarity.py:108-116: re-push the seed while it stays above the threshold, no enqueue
             while (ok) {
                 const T ru2 = st[seed].r;
                 if (!(ru2 / seed_d >= eps)) break;
-                push(seed, HOT_NONE, seed_d, ru2, seed_b, seed_e, false);
+                push(seed, HOT_NONE, WATCH_NONE, seed_d, ru2, seed_b, seed_e, false, nullptr);
             }
         }
 
@@ -672,9 +726,10 @@ __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
             const uint32_t bn = navail < (uint32_t)WAVE ? navail : (uint32_t)WAVE;
             const bool valid = (uint32_t)lane < bn;
             int32_t u_l = 0;
-            uint32_t h_l = HOT_NONE;
+            uint32_t h_l = HOT_NONE, w_l = WATCH_NONE;
             T r_l = T(0), d_l = T(1);
             int64_t rb_l = 0, re_l = 0;
+            for (int i = lane; i < WATCH_SLOTS; i += WAVE) wkey[i] = -1;
             if (valid) {
                 const QEntry e = q[(head + lane) & qmask];
                 u_l = e.v;
@@ -683,44 +738,60 @@ __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
                 r_l = read_r(u_l, h_l);       // queued nodes were deposited to in this epoch: live
                 rb_l = g.indptr[u_l];
                 re_l = g.indptr[u_l + 1];
+                // enter the node into the watch table (a node queued twice shares one slot)
+                for (uint32_t ws = watch_hash(u_l);; ws = (ws + 1) & (WATCH_SLOTS - 1)) {
+                    const int32_t old = atomicCAS(wkey + ws, -1, u_l);
+                    if (old == -1 || old == u_l) { w_l = ws; break; }
+                }
+                wval[w_l] = r_l;
             }
             head += bn;    // the batch lives in registers from here on
             int consumed = 0;
             bool pass = valid && (r_l / d_l >= eps);                                  // similarity.py:204
+            // Row data fetched ahead: while entry i is pushed, the first step of the row of the NEXT passing entry
+            // (as things stand before the push) is already on its way; if that entry is indeed the next one pushed
+            // -- the push may lift an earlier entry over the threshold instead -- its push starts with the data in
+            // registers.  Graph arrays only: nothing about the result depends on the guess.
+            RowStage<T, TILES> Rp, Rn;
+            int pre_lane = -1;
             for (;;) {
                 const uint64_t m = __ballot(pass && lane >= consumed);
                 if (m == 0) break;
                 const int i = __ffsll((unsigned long long)m) - 1;
-                const int32_t u = __shfl(u_l, i, WAVE);
-                const uint32_t hu = (uint32_t)__shfl((int)h_l, i, WAVE);
-                const T du = shfl_real<T>(d_l, i);
-                T ru = shfl_real<T>(r_l, i);
-                consumed = i + 1;
-                if (P.refresh_failing_only) {
-                    // r of a passing entry can only have grown since it was read -- unless the node was pushed in
-                    // between (the queue holds duplicates): read it again, it is this entry's pop time now
-                    ru = read_r(u, hu);
-                    if (!(ru / du >= eps)) {
-                        if (lane == i) pass = false;
-                        continue;
+                const bool use_pre = pre_lane == i;
+                int next_lane = -1;
+                if (P.prefetch_next) {
+                    const uint64_t m2 = m & (m - 1);
+                    if (m2) {
+                        const int j = __ffsll((unsigned long long)m2) - 1;
+                        const int64_t rbj = shfl_i64(rb_l, j), rej = shfl_i64(re_l, j);
+                        if (rej > rbj) { load_row_at(rbj, rej, Rn); next_lane = j; }
                     }
                 }
+                const int32_t u = __shfl(u_l, i, WAVE);
+                const uint32_t hu = (uint32_t)__shfl((int)h_l, i, WAVE);
+                const uint32_t wu = (uint32_t)__shfl((int)w_l, i, WAVE);
+                const T du = shfl_real<T>(d_l, i);
+                const T ru = shfl_real<T>(r_l, i);           // current: refreshed from the watch table after every push
+                consumed = i + 1;
                 const int64_t rb = shfl_i64(rb_l, i);
                 const int64_t re = shfl_i64(re_l, i);
-                push(u, hu, du, ru, rb, re, true);
+                push(u, hu, wu, du, ru, rb, re, true, use_pre ? &Rp : nullptr);
                 if (VAR == 2) {
                     // similarity.py:136-144: re-push the same node while it stays above the threshold
                     while (ok) {
                         const T ru2 = st[u].r;
                         if (!(ru2 / du >= eps)) break;
-                        push(u, hu, du, ru2, rb, re, false);
+                        push(u, hu, wu, du, ru2, rb, re, false, nullptr);
                     }
                 }
                 if (!ok) break;
-                // re-test the entries not consumed yet: all of them (every test then sees r at its pop time), or
-                // only those that did not pass (a passing entry is re-read when its turn comes)
-                if (valid && lane >= consumed && !(P.refresh_failing_only && pass)) {
-                    r_l = read_r(u_l, h_l);
+                Rp = Rn;
+                pre_lane = next_lane;
+                // every test must see r at its pop time: the push has left the new r of every batch node it touched
+                // (and of u itself) in the watch table
+                if (valid && lane >= consumed) {
+                    r_l = P.watch ? wval[w_l] : read_r(u_l, h_l);     // (watch off: the A/B arm, a gather from HBM)
                     pass = r_l / d_l >= eps;
                 }
             }
@@ -733,7 +804,7 @@ __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
         int32_t emitted = 0, support = 0;
         const int32_t ncand = nsup;
         unsigned long long off = 0;
-        if (MODE == 0 && ok) {
+        if (MODE != 1 && ok) {
             const int64_t sb = g.indptr[seed], se = g.indptr[seed + 1];
             T thr = st[seed].s / st[seed].d;
             bool miss = st[seed].s == T(0), selfloop = false;
@@ -761,8 +832,22 @@ __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
             }
             thr = wave_min_real<T>(thr);
             const bool missing = __ballot(miss) != 0;
-            if (VAR == 0 && missing) sta = ST_MISSING_BASE;
-            else if (VAR != 0 && (missing || __ballot(selfloop) != 0)) {
+            const bool any_selfloop = __ballot(selfloop) != 0;
+            // MODE 2 (arcte.pyx:125-241): the candidate list holds EVERY node of the support (cand_thr = 0), each of
+            // them hands (node, seed, s/in_degree) to the centrality accumulation (arcte.pyx:190-191); a closed
+            // neighbourhood that is not inside the support emits nothing (the scan of :200-208 never completes)
+            // instead of failing; the neighbourhood is a set there (:196-198): a self-loop does not count twice.
+            unsigned long long coff = 0;
+            bool contribute = false;
+            if (MODE == 2) {
+                if (lane == 0) coff = atomicAdd(P.contrib_cursor, (unsigned long long)nsup);
+                coff = bcast_u64(coff);
+                contribute = coff + (unsigned long long)nsup <= P.contrib_cap;
+                if (!contribute) sta = ST_CONTRIB_OVERFLOW;
+            }
+            const int64_t base_size = (MODE == 2) ? (se - sb) + (any_selfloop ? 0 : 1) : (se - sb) + 1;
+            if (MODE != 2 && VAR == 0 && missing) sta = ST_MISSING_BASE;
+            else if (VAR != 0 && (missing || any_selfloop)) {
                 // arcte.py:129-133: the PageRank flavours skip a seed whose closed neighbourhood is not inside
                 // the support; intersect1d de-duplicates, so a seed with a self-loop never passes the guard
                 support = nfirst;
@@ -786,14 +871,22 @@ __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
                             }
                         }
                         if (!chip) { sv = st[v].s; dv = st[v].d; }
-                        sel = (sv / dv) >= thr;                               // arcte.py:363-367
+                        const T xn = sv / dv;
+                        sel = xn >= thr;                                      // arcte.py:363-367
+                        if (MODE == 2) {
+                            sel = sel && !missing;
+                            if (contribute) {
+                                P.contrib_key[coff + i] = ((uint64_t)(uint32_t)v << 32) | (uint32_t)seed;
+                                P.contrib_val[coff + i] = (double)xn;
+                            }
+                        }
                     }
                     const uint64_t ms = __ballot(sel);
                     if (sel) sup[cnt + lane_below(ms)] = v;               // in place: cnt <= i0
                     cnt += __popcll(ms);
                 }
                 support = nfirst;
-                if ((int64_t)cnt > (se - sb) + 1) {                                   // arcte.py:370
+                if ((int64_t)cnt > base_size && sta == ST_OK) {                       // arcte.py:370 / arcte.pyx:211
                     if (lane == 0) off = atomicAdd(P.raw_cursor, (unsigned long long)cnt);
                     off = bcast_u64(off);
                     if (off + (unsigned long long)cnt > P.rawcap) sta = ST_OUTPUT_OVERFLOW;

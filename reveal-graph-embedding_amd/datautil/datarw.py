@@ -6,14 +6,9 @@ import scipy.sparse as spsp
 from reveal_graph_embedding_amd.common import get_file_row_generator
 
 
-def read_adjacency_matrix(file_path, separator, undirected):
-    """
-    Reads an edge list (`source<sep>target<sep>weight` per line, lines starting with '#' skipped) and
-    returns (adjacency_matrix as scipy COO float64, node_to_id).  Node ids are renumbered in first-seen
-    order, source before target (reference :87-92); node_to_id maps the new numbers back.  With
-    `undirected`, every non-loop edge also gets its reciprocal (:105-109).  Duplicate edges stay
-    duplicate COO entries (they are summed when the matrix is converted, as in the reference).
-    """
+def read_edge_triplets(file_path, separator, undirected):
+    """The edge list as flat arrays: (number_of_nodes, row int32, col int32, data float64, node_to_id).  Same parsing
+    as read_adjacency_matrix (reference :54-120), without wrapping the result in a scipy matrix."""
     id_to_node = dict()
     row, col, data = [], [], []
     for file_row in get_file_row_generator(file_path, separator):
@@ -31,8 +26,20 @@ def read_adjacency_matrix(file_path, separator, undirected):
             data.append(edge_weight)
     number_of_nodes = len(id_to_node)
     node_to_id = dict(zip(id_to_node.values(), id_to_node.keys()))
-    adjacency_matrix = spsp.coo_matrix((np.array(data, dtype=np.float64),
-                                        (np.array(row, dtype=np.int64), np.array(col, dtype=np.int64))),
+    return (number_of_nodes, np.array(row, dtype=np.int32), np.array(col, dtype=np.int32), np.array(data, dtype=np.float64),
+            node_to_id)
+
+
+def read_adjacency_matrix(file_path, separator, undirected):
+    """
+    Reads an edge list (`source<sep>target<sep>weight` per line, lines starting with '#' skipped) and
+    returns (adjacency_matrix as scipy COO float64, node_to_id).  Node ids are renumbered in first-seen
+    order, source before target (reference :87-92); node_to_id maps the new numbers back.  With
+    `undirected`, every non-loop edge also gets its reciprocal (:105-109).  Duplicate edges stay
+    duplicate COO entries (they are summed when the matrix is converted, as in the reference).
+    """
+    number_of_nodes, row, col, data, node_to_id = read_edge_triplets(file_path, separator, undirected)
+    adjacency_matrix = spsp.coo_matrix((data, (row.astype(np.int64), col.astype(np.int64))),
                                        shape=(number_of_nodes, number_of_nodes))
     return adjacency_matrix, node_to_id
 
@@ -44,3 +51,18 @@ def write_features(file_path, features, separator, node_to_id):
     with open(file_path, "w") as f:
         f.writelines(str(ids[r]) + separator + str(c) + separator + str(int(v)) + "\n"
                      for r, c, v in zip(features.row.tolist(), features.col.tolist(), features.data.tolist()))
+
+
+def write_feature_triplets(file_path, indptr, indices, doubled_diagonal_nodes, separator, node_to_id):
+    """write_features (reference :123-143) for arcte()'s matrix given as raw CSR arrays: one line per stored entry in
+    row-major order, `<original node id><sep><column><sep><value>` with value 1, or 2 on the diagonal of the nodes in
+    `doubled_diagonal_nodes` (identity + ones on a self-loop, arcte.py:676-679)."""
+    doubled = set(int(i) for i in doubled_diagonal_nodes)
+    with open(file_path, "w") as f:
+        for i in range(len(indptr) - 1):
+            node_id = str(node_to_id[i])
+            cols = indices[indptr[i]:indptr[i + 1]].tolist()
+            if i in doubled:
+                f.writelines(node_id + separator + str(c) + separator + ("2" if c == i else "1") + "\n" for c in cols)
+            else:
+                f.writelines(node_id + separator + str(c) + separator + "1\n" for c in cols)

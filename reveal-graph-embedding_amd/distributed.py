@@ -136,3 +136,63 @@ def arcte_distributed(adjacency_matrix, rho, epsilon, device=None, group=None, r
     ones = adjacency_matrix.copy()
     ones.data = np.ones_like(ones.data, dtype=np.float64)
     return sparse.hstack([identity + ones, local]).tocsr()
+
+
+def arcte_and_centrality_distributed(adjacency_matrix, rho, epsilon, device=None, group=None, run_block=None):
+    """arcte_and_centrality (cython_opt/arcte.pyx:125-241) over the ranks of `group`.
+
+    The seeds are the nodes in index order and the column numbering is a running counter over them, so rank r takes
+    the contiguous node block [r*n/world, (r+1)*n/world); the partial centrality vectors are summed by ONE float64
+    all-reduce over xGMI (RCCL) -- per node this adds the ranks' partial sums instead of folding seed by seed, so the
+    result agrees with the one-GPU run to rounding (~1e-15 relative), not bit for bit -- and the communities are
+    gathered on rank 0, which numbers the columns in rank order.  Rank 0 returns (features, centrality), the others
+    (None, centrality).  `run_block(adjacency_matrix, lo, hi, rho, epsilon) -> (colptr, rows, partial_centrality)`
+    overrides the compute step (CPU tests)."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from reveal_graph_embedding_amd.embedding.common import normalize_community_features
+
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    a = sparse.csr_matrix(adjacency_matrix, dtype=np.float64)
+    n = a.shape[0]
+    lo, hi = rank * n // world, (rank + 1) * n // world
+    on_gpu = dist.get_backend(group) == "nccl"
+    if device is None:
+        device = int(os.environ.get("LOCAL_RANK", "0"))
+    if on_gpu:
+        torch.cuda.set_device(device)
+    if run_block is not None:
+        colptr, rows, partial = run_block(a, lo, hi, rho, epsilon)
+        w_host = None
+    else:
+        from reveal_graph_embedding_amd import _native
+        with _native.Context.from_adjacency(a.indptr, a.indices, a.data, device=device) as ctx:
+            ctx.run_centrality(rho, epsilon, lo, hi)
+            colptr, rows = ctx.fetch()
+            partial = ctx.centrality()
+            w_host = ctx.transition() if rank == 0 else None
+    where = "cuda:%d" % device if on_gpu else "cpu"
+    cent_t = torch.from_numpy(np.ascontiguousarray(partial, dtype=np.float64)).to(where)
+    dist.all_reduce(cent_t, op=dist.ReduceOp.SUM, group=group)           # the one collective of this driver
+    centrality = cent_t.cpu().numpy()
+    counts_t = torch.from_numpy(np.diff(colptr).astype(np.int64)).to(where)
+    rows_t = torch.from_numpy(np.ascontiguousarray(rows, dtype=np.int32)).to(where)
+    gathered = gather_shards(counts_t, rows_t, dst=0, group=group)
+    if rank != 0:
+        return None, centrality
+    sizes = np.concatenate([np.asarray(c.cpu().numpy(), dtype=np.int64) for c, _ in gathered])
+    members = np.concatenate([np.asarray(r.cpu().numpy(), dtype=np.int64) for _, r in gathered])
+    emitted = np.flatnonzero(sizes)
+    cols = np.repeat(np.arange(emitted.size), sizes[emitted])             # arcte.pyx:213-215
+    local = sparse.coo_matrix((np.ones(members.size), (members, cols)), shape=(n, emitted.size))
+    if w_host is None:
+        w = run_block.transition(a)
+    else:
+        w = sparse.csr_matrix((w_host[2], w_host[1], w_host[0]), shape=(n, n))
+    base = sparse.csr_matrix(sparse.eye(n, n, dtype=np.float64)) + w      # arcte.pyx:227-228 (see the oracle's note)
+    features = sparse.hstack([base, local]).tocsr() if emitted.size else base
+    if run_block is not None and getattr(run_block, "normalize", None) is not None:
+        return run_block.normalize(features), centrality
+    return normalize_community_features(features), centrality

@@ -1,0 +1,38 @@
+"""Mirror of reveal_graph_embedding/embedding/arcte/cython_opt/arcte.pyx (reference lines 20-241): the reference's
+older single-process ARCTE driver -- raw epsilon, every node with out-edges a seed, columns numbered by a running
+counter, tf-idf + row normalised output -- and its centrality-collecting twin.  Propagation, the centrality
+accumulation, the assembly of the feature matrix and its normalisation all run on the GPU."""
+import numpy as np
+import scipy.sparse as sparse
+
+from reveal_graph_embedding_amd import _native
+
+
+def _run(adjacency_matrix, rho, epsilon, device):
+    a = sparse.csr_matrix(adjacency_matrix, dtype=np.float64)
+    with _native.Context.from_adjacency(a.indptr, a.indices, a.data, device=device) as ctx:
+        ctx.run_centrality(rho, epsilon)
+        centrality = ctx.centrality()
+        with _native.Features.from_result(ctx, with_base_block=True) as f:
+            f.normalize_columns().normalize_rows()                   # normalize_community_features, arcte.pyx:238
+            features = f.to_scipy()
+    return features, centrality
+
+
+def arcte(adjacency_matrix, rho, epsilon, device=0):
+    """
+    Extracts local community features for all graph nodes (reference arcte.pyx:20-122).
+
+    Inputs:  - A in R^(nxn): adjacency matrix.   - rho: restart probability.   - epsilon: approximation threshold.
+    Outputs: - X in R^(nxC_n): the latent space embedding: [I + W | local communities], tf-idf and row normalised.
+    """
+    return _run(adjacency_matrix, rho, epsilon, device)[0]
+
+
+def arcte_and_centrality(adjacency_matrix, rho, epsilon, device=0):
+    """
+    arcte() plus the RCT centrality vector (reference arcte.pyx:125-241): the sum over all seeds of their degree-
+    normalised similarity slices (1.0 for nodes without out-edges).  The reference returns a 1 x n np.matrix (its
+    `centrality += s_sparse` silently turns the vector into one); this returns the flat float64 vector.
+    """
+    return _run(adjacency_matrix, rho, epsilon, device)

@@ -93,3 +93,49 @@ def test_sharded_arcte_with_hip_compute_and_gloo_transport(tmp_path):
     z = np.load(out)
     f = sparse.csr_matrix((z["data"], z["indices"], z["indptr"]), shape=tuple(z["shape"]))
     assert_same_sparse(f, load_golden("rmat2000")["feat1"])
+
+
+def _centrality_worker(rank, world, port, name, out_path):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import oracle
+    from reveal_graph_embedding_amd.distributed import arcte_and_centrality_distributed
+    from test_centrality_weighting_cpu import load_centrality
+    g = load_centrality(name)
+
+    def run_block(adjacency, lo, hi, rho, eps):
+        return oracle.centrality_block(adjacency, rho, eps, lo, hi)
+    run_block.transition = lambda a: oracle.get_natural_random_walk_matrix(a)[0]
+    run_block.normalize = oracle.normalize_community_features          # no GPU in this test: the oracle's restatement
+
+    f, c = arcte_and_centrality_distributed(g["adjacency"], float(g["rho"]), float(g["epsilon"]), run_block=run_block)
+    assert c.shape == (g["adjacency"].shape[0],)
+    np.save(out_path + ".c%d.npy" % rank, c)
+    if rank == 0:
+        f.sort_indices()
+        np.savez(out_path, indptr=f.indptr, indices=f.indices, data=f.data, shape=np.array(f.shape))
+    else:
+        assert f is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,name", [(2, "ba300"), (3, "weighted")])
+def test_sharded_arcte_and_centrality(tmp_path, world, name):
+    """The one collective of the centrality driver: an all-reduce of the float64[n] partial sums (gloo here, RCCL on
+    GPUs), plus the usual gather.  Every rank ends with the same centrality; rank 0's features equal the reference's."""
+    import scipy.sparse as sparse
+    from test_centrality_weighting_cpu import assert_close_sparse, load_centrality
+    out = str(tmp_path / "f.npz")
+    mp.spawn(_centrality_worker, args=(world, _free_port(), name, out), nprocs=world, join=True)
+    g = load_centrality(name)
+    z = np.load(out)
+    f = sparse.csr_matrix((z["data"], z["indices"], z["indptr"]), shape=tuple(z["shape"]))
+    assert_close_sparse(f, g["features"], 1e-13)
+    cs = [np.load(out + ".c%d.npy" % r) for r in range(world)]
+    for c in cs[1:]:
+        assert np.array_equal(c, cs[0])
+    np.testing.assert_allclose(cs[0], g["centrality"], rtol=1e-13, atol=0)
