@@ -117,6 +117,9 @@ def main():
     ap.add_argument("--variant", choices=["arcte", "pagerank", "lazy"], default="arcte",
                     help="push flavour (default: ARCTE's cumulative PageRank difference = the BASELINE metric)")
     ap.add_argument("--float32", action="store_true", help="float32 arithmetic (tolerance sweep only; not the metric)")
+    ap.add_argument("--verify", action="store_true",
+                    help="after the timed steps, rank 0 merges what it gathered into arcte()'s n x 2n matrix and reports the "
+                         "SHA-256 of its canonical CSR (tests compare it with the reference's own run)")
     args = ap.parse_args()
 
     import torch
@@ -152,28 +155,28 @@ def main():
 
     from reveal_graph_embedding_amd import _native
     from reveal_graph_embedding_amd.distributed import gather_shards, shard_seeds
-    from reveal_graph_embedding_amd.eps_randomwalk.transition import get_natural_random_walk_matrix
-    from reveal_graph_embedding_amd.embedding.arcte.arcte import seed_nodes
 
+    # the adjacency matrix goes to the GPU as it is; transition matrix, degree vectors and seed list are made there
     adjacency = load_graph(args.nodes, args.edges, 0, local_rank, barrier)
-    w, out_degree, in_degree = get_natural_random_walk_matrix(adjacency)
-    seeds = seed_nodes(adjacency)
-    shard = shard_seeds(seeds, args.shards, rank)
     nnz = int(adjacency.nnz)
+    w_indptr, w_indices = adjacency.indptr, adjacency.indices          # pattern of W = pattern of A (--verify)
+    ctx = _native.Context.from_adjacency(adjacency.indptr, adjacency.indices, adjacency.data, device=gpu, n_slots=args.slots)
     del adjacency
-    ctx = _native.Context(w.indptr, w.indices, w.data, out_degree, in_degree, device=gpu, n_slots=args.slots)
+    seeds = ctx.seed_list()
+    shard = shard_seeds(seeds, args.shards, rank)
     info = ctx.info()
     log("[bench] rank %d: n=%d nnz=%d seeds=%d shard=%d slots=%d device_bytes=%.1f GB" % (
         rank, args.nodes, nnz, seeds.size, shard.size, info["slots"], info["device_bytes"] / 1e9))
 
     gathered_rows = 0
+    gathered = None
     variant = {"arcte": _native.ARCTE, "pagerank": _native.PAGERANK, "lazy": _native.LAZY_PAGERANK}[args.variant]
     run_rho = (args.rho * 0.5) / (1 - 0.5 * args.rho) if args.variant == "lazy" else args.rho   # arcte.py:109
     if args.float32:
         ctx.set_float32(True)
 
     def step():
-        nonlocal gathered_rows
+        nonlocal gathered_rows, gathered
         ctx.run_seeds(shard, run_rho, args.epsilon, use_effective_epsilon=True, variant=variant)
         if world > 1:
             _, total = ctx.result_sizes()
@@ -187,6 +190,7 @@ def main():
             out = gather_shards(counts_t, rows_t, dst=0)
             if out is not None:
                 gathered_rows = sum(int(r.numel()) for _, r in out)
+                gathered = out
 
     for _ in range(args.warmup):
         step()
@@ -213,6 +217,30 @@ def main():
     st = ctx.stats()
     tm = ctx.timing()
     _, total_rows = ctx.result_sizes()
+    if world > 1:
+        rows_t = torch.tensor([total_rows], dtype=torch.int64, device=comm_dev)
+        dist.all_reduce(rows_t, op=dist.ReduceOp.SUM)
+        emitted_all = int(rows_t.item())
+    else:
+        emitted_all = int(total_rows)
+    merged_sha = None
+    if args.verify and rank == 0:
+        import hashlib
+        import scipy.sparse as sparse
+        from reveal_graph_embedding_amd.distributed import merge_shards
+        if world > 1 and args.gather == "rows" and args.shards == world:
+            local = merge_shards(args.nodes, seeds, world, gathered)
+        else:
+            colptr_v, rows_v = ctx.fetch()
+            local = merge_shards(args.nodes, shard, 1, [(np.diff(colptr_v), rows_v)])
+        pattern = sparse.csr_matrix((np.ones(w_indices.size), w_indices, w_indptr), shape=(args.nodes, args.nodes))
+        f = sparse.hstack([sparse.csr_matrix(sparse.eye(args.nodes, args.nodes)) + pattern, local]).tocsr()
+        f.sum_duplicates()
+        f.sort_indices()
+        h = hashlib.sha256()
+        h.update(f.indptr.astype(np.int64).tobytes())
+        h.update(f.indices.astype(np.int64).tobytes())
+        merged_sha = h.hexdigest()
     t = time.perf_counter()
     ctx.fetch()                      # D2H of the step's result: reported beside the metric, never inside it
     fetch_ms = (time.perf_counter() - t) * 1e3
@@ -267,7 +295,7 @@ def main():
                 "slots_per_gpu": info["slots"], "waves_per_cu": info["waves_per_cu"],
                 "hot_values_per_wave": info["hot_values_per_wave"],
                 "kernel_source_id": kernel_source_id(),
-                "emitted_rows_rank0": int(total_rows),
+                "emitted_rows_rank0": int(total_rows), "emitted_rows_all_ranks": emitted_all, "merged_sha256": merged_sha,
                 "gathered_rows_rank0": int(gathered_rows),
                 "per_seed": {k: st[k] / max(shard.size, 1) for k in ("pushes", "edges", "enqueues", "support")},
                 "reruns": st["reruns"],
@@ -290,6 +318,9 @@ def main():
             # the 52/36/4/36-byte model prices ARCTE's push (s and r per edge); the PageRank flavours move less
             result["roofline"]["note"] = "algorithmic-byte model is ARCTE's; indicative only for this flavour"
         if world == 1 and args.cpu_seconds > 0 and args.variant == "arcte" and not args.float32:
+            import scipy.sparse as sparse
+            t_indptr, t_indices, t_data, out_degree, in_degree = ctx.transition()
+            w = sparse.csr_matrix((t_data, t_indices, t_indptr), shape=(args.nodes, args.nodes))
             result["cpu_baseline"] = cpu_baseline(w, out_degree, in_degree, shard, args.rho, args.epsilon, args.cpu_seconds)
         else:
             result["cpu_baseline"] = None

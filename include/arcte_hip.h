@@ -107,6 +107,11 @@ int arcte_hip_fetch_seed_list(arcte_hip_ctx *ctx, int64_t *seeds);
 int arcte_hip_epsilon_effective(arcte_hip_ctx *ctx, const int64_t *seeds, int64_t nseeds,
                                 double epsilon, double *eps_out);
 
+/* The same rule for ONE seed given as the reference's function takes it (arcte.py:26: seed degree and the vector of
+ * its neighbours' degrees), without a context: the scalar call surface of calculate_epsilon_effective. */
+int arcte_hip_epsilon_effective_scalar(int device, double epsilon, double seed_degree,
+                                       const double *neighbor_degrees, int64_t n_neighbors, double *eps_out);
+
 /*
  * The loop body of arcte_worker (embedding/arcte/arcte.py:337-376) for every seed:
  * effective epsilon -> fast_approximate_cumulative_pagerank_difference

@@ -32,6 +32,7 @@ SIGNATURES = {
     "arcte_hip_fetch_transition": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "arcte_hip_fetch_seed_list": (C.c_int, [C.c_void_p, C.c_void_p]),
     "arcte_hip_epsilon_effective": (C.c_int, [C.c_void_p, _i64p, C.c_int64, C.c_double, _f64p]),
+    "arcte_hip_epsilon_effective_scalar": (C.c_int, [C.c_int, C.c_double, C.c_double, _f64p, C.c_int64, C.POINTER(C.c_double)]),
     "arcte_hip_run_seeds": (C.c_int, [C.c_void_p, _i64p, C.c_int64, C.c_double, C.c_double, C.c_int]),
     "arcte_hip_run_seeds_variant": (C.c_int, [C.c_void_p, _i64p, C.c_int64, C.c_double, C.c_double, C.c_int, C.c_int,
                                               C.c_double]),
@@ -111,6 +112,14 @@ def device_count():
     n = C.c_int(0)
     _check(lib().arcte_hip_device_count(C.byref(n)))
     return n.value
+
+
+def epsilon_effective_scalar(epsilon, seed_degree, neighbor_degrees, device=0):
+    """calculate_epsilon_effective (arcte.py:26-50) for one seed, by the kernel the bulk path uses."""
+    nd = np.ascontiguousarray(neighbor_degrees, dtype=np.float64).reshape(-1)
+    out = C.c_double(0)
+    _check(lib().arcte_hip_epsilon_effective_scalar(int(device), float(epsilon), float(seed_degree), nd, nd.size, C.byref(out)))
+    return out.value
 
 
 def stream_bandwidth(device=0, nbytes=4 << 30):

@@ -254,7 +254,6 @@ uint32_t hot_values_per_wave(const arcte_hip_ctx *c, size_t value_bytes)
     const size_t reserve = (size_t)std::max(0, env_int("ARCTE_HIP_LDS_RESERVE_KB", 8)) * 1024;
     size_t per_wave = (LDS_PER_CU - std::min(reserve, LDS_PER_CU / 2)) / (size_t)c->waves_per_cu;
     per_wave = per_wave / 1024 * 1024;
-    per_wave -= std::min(per_wave, WATCH_SLOTS * (sizeof(int32_t) + value_bytes));     // the watch table sits behind the hot table
     uint64_t k = per_wave / value_bytes;
     k = std::min<uint64_t>(k, (uint64_t)c->hot_ranked);
     if (cap > 0) k = std::min<uint64_t>(k, (uint64_t)cap);
@@ -278,13 +277,13 @@ int launch_seeds_v(arcte_hip_ctx *c, PushParams P, int64_t nwork)
     P.hotK = 0;
     if (MODE == 1) {
         // works on the dense vectors the host placed in slot 0: exactly one wavefront may run, all state in HBM
-        return launch_with_lds(k_arcte_seeds<MODE, VAR, T, 2, false>, 1, WAVE, watch_bytes<T>(), c->stream, P);
+        return launch_with_lds(k_arcte_seeds<MODE, VAR, T, 2, false>, 1, WAVE, 0, c->stream, P);
     }
     const int wpb = c->waves_per_block;
     const int64_t waves = std::min<int64_t>(c->slots, std::max<int64_t>(nwork, 1));
     const int blocks = (int)((waves + wpb - 1) / wpb);
     P.hotK = hot_values_per_wave(c, sizeof(T));
-    const size_t lds = (size_t)wpb * (P.hotK * sizeof(T) + watch_bytes<T>());
+    const size_t lds = (size_t)wpb * P.hotK * sizeof(T);
     if (P.hotK == 0) return launch_with_lds(k_arcte_seeds<MODE, VAR, T, 2, false>, blocks, wpb * WAVE, lds, c->stream, P);
     if (c->tiles == 4) return launch_with_lds(k_arcte_seeds<MODE, VAR, T, 4, true>, blocks, wpb * WAVE, lds, c->stream, P);
     return launch_with_lds(k_arcte_seeds<MODE, VAR, T, 2, true>, blocks, wpb * WAVE, lds, c->stream, P);
@@ -299,7 +298,7 @@ int launch_centrality(arcte_hip_ctx *c, PushParams P, int64_t nwork)
     const int64_t waves = std::min<int64_t>(c->slots, std::max<int64_t>(nwork, 1));
     const int blocks = (int)((waves + wpb - 1) / wpb);
     P.hotK = hot_values_per_wave(c, sizeof(double));
-    const size_t lds = (size_t)wpb * (P.hotK * sizeof(double) + watch_bytes<double>());
+    const size_t lds = (size_t)wpb * P.hotK * sizeof(double);
     if (P.hotK == 0) return launch_with_lds(k_arcte_seeds<2, 0, double, 2, false>, blocks, wpb * WAVE, lds, c->stream, P);
     return launch_with_lds(k_arcte_seeds<2, 0, double, 2, true>, blocks, wpb * WAVE, lds, c->stream, P);
 }
@@ -871,6 +870,53 @@ int arcte_hip_epsilon_effective(arcte_hip_ctx *c, const int64_t *seeds, int64_t 
 // its contributions could otherwise be counted twice -- after growing whatever was too small.
 constexpr int RC_RETRY_BATCH = 1, RC_CONTRIB_FULL = 2;
 
+int arcte_hip_epsilon_effective_scalar(int device, double epsilon, double seed_degree, const double *neighbor_degrees, int64_t m,
+                                       double *eps_out)
+{
+    if (!eps_out || m < 0 || (m && !neighbor_degrees)) return fail(ARCTE_HIP_EINVAL, "bad argument");
+    if (m == 0) return fail(ARCTE_HIP_EGRAPH, "zero-size array to reduction operation maximum which has no identity (arcte.py:39)");
+    if (m >= ((int64_t)1 << 31) - 1) return fail(ARCTE_HIP_EINVAL, "too many neighbours");
+    HIP_TRY(hipSetDevice(device));
+    // a star: node 0 carries seed_degree, nodes 1..m the neighbour degrees -- the shapes the bulk kernels walk
+    std::vector<int64_t> indptr_h((size_t)m + 2, m);
+    indptr_h[0] = 0;
+    std::vector<int32_t> indices_h((size_t)m);
+    for (int64_t k = 0; k < m; k++) indices_h[(size_t)k] = (int32_t)(k + 1);
+    std::vector<double> od_h((size_t)m + 1);
+    od_h[0] = seed_degree;
+    memcpy(od_h.data() + 1, neighbor_degrees, (size_t)m * sizeof(double));
+    DevBuf<int64_t> indptr_d;
+    DevBuf<int32_t> indices_d, seed_d, big_d;
+    DevBuf<double> od_d, out_d;
+    int rc = [&]() -> int {
+        HIP_TRY(indptr_d.alloc(m + 2));
+        HIP_TRY(indices_d.alloc(m));
+        HIP_TRY(od_d.alloc(m + 1));
+        HIP_TRY(out_d.alloc(1));
+        HIP_TRY(seed_d.alloc(1));
+        HIP_TRY(big_d.alloc(1));
+        HIP_TRY(hipMemcpy(indptr_d.p, indptr_h.data(), (m + 2) * sizeof(int64_t), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(indices_d.p, indices_h.data(), m * sizeof(int32_t), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(od_d.p, od_h.data(), (m + 1) * sizeof(double), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemset(seed_d.p, 0, sizeof(int32_t)));
+        HIP_TRY(hipMemset(big_d.p, 0, sizeof(int32_t)));
+        GraphDev g = {};
+        g.n = m + 1;
+        g.indptr = indptr_d.p;
+        g.indices = indices_d.p;
+        g.out_degree = od_d.p;
+        if (m >= EPS_BIG_ROW)
+            hipLaunchKernelGGL(k_epsilon_effective_big, dim3(1), dim3(EPS_BIG_WAVES * WAVE), 0, 0, g, seed_d.p, big_d.p, (int64_t)1, epsilon, out_d.p);
+        else
+            hipLaunchKernelGGL(k_epsilon_effective, dim3(1), dim3(BLOCK), 0, 0, g, seed_d.p, (int64_t)1, epsilon, out_d.p);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpy(eps_out, out_d.p, sizeof(double), hipMemcpyDeviceToHost));
+        return 0;
+    }();
+    indptr_d.release(); indices_d.release(); seed_d.release(); big_d.release(); od_d.release(); out_d.release();
+    return rc;
+}
+
 static int run_seeds_impl(arcte_hip_ctx *c, const int64_t *seeds, int64_t nseeds, double rho, double epsilon,
                           int use_effective_epsilon, int variant, double lazy, int mode = 0)
 {
@@ -1013,8 +1059,6 @@ static int run_seeds_impl(arcte_hip_ctx *c, const int64_t *seeds, int64_t nseeds
         P.sup = c->sup.p;
         P.qcap = c->qcap;
         P.max_pushes = max_pushes_limit();
-        P.prefetch_next = env_int("ARCTE_HIP_PREFETCH", 1) ? 1 : 0;
-        P.watch = env_int("ARCTE_HIP_WATCH", 1) ? 1 : 0;
         P.raw = c->raw.p;
         P.rawcap = c->raw.count;
         P.raw_cursor = c->counters.p + 1;
@@ -1542,9 +1586,7 @@ static int similarity_slice_impl(arcte_hip_ctx *c, int64_t seed, double rho, dou
             P.sup = c->sup.p;
             P.qcap = c->qcap;
             P.max_pushes = max_pushes_limit();
-            P.prefetch_next = env_int("ARCTE_HIP_PREFETCH", 1) ? 1 : 0;
-        P.watch = env_int("ARCTE_HIP_WATCH", 1) ? 1 : 0;
-            P.raw = nullptr;
+                P.raw = nullptr;
             P.rawcap = 0;
             P.raw_cursor = c->counters.p + 1;
             P.out_off = off_d.p;
@@ -2043,7 +2085,7 @@ int arcte_hip_launch_occupancy(arcte_hip_ctx *c, int *workgroups_per_cu)
     if (!c || !workgroups_per_cu) return fail(ARCTE_HIP_EINVAL, "bad argument");
     HIP_TRY(hipSetDevice(c->device));
     const uint32_t k = hot_values_per_wave(c, sizeof(double));
-    const size_t lds = (size_t)c->waves_per_block * (k * sizeof(double) + watch_bytes<double>());
+    const size_t lds = (size_t)c->waves_per_block * k * sizeof(double);
     int per_cu = 0;
     if (k == 0) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (k_arcte_seeds<0, 0, double, 2, false>), c->waves_per_block * WAVE, lds));
     else {

@@ -334,15 +334,6 @@ template <> __device__ __forceinline__ float hot_moved<float>() { return __uint_
 __device__ __forceinline__ bool is_moved(double x) { return __double_as_longlong(x) == 0x7FF8DEAD0000BEEFll; }
 __device__ __forceinline__ bool is_moved(float x) { return __float_as_uint(x) == 0x7FC0BEEFu; }
 
-// Watch table (LDS, per wavefront): the nodes of the pop batch in flight and their CURRENT r.  Every deposit of a
-// push looks its target up here and, on a hit, leaves the new r; the re-test of the not yet consumed batch entries
-// after a push (similarity.py:204 needs r at pop time) then reads LDS instead of gathering from HBM again -- one
-// dependent memory round trip less per push.  256 slots for at most 64 nodes: open addressing, linear probing.
-constexpr int WATCH_SLOTS = 256;
-constexpr uint32_t WATCH_NONE = 0xFFFFFFFFu;
-template <typename T> constexpr size_t watch_bytes() { return WATCH_SLOTS * (sizeof(int32_t) + sizeof(T)); }
-__device__ __forceinline__ uint32_t watch_hash(int32_t v) { return ((uint32_t)v * 2654435761u) >> 24; }
-
 struct PushParams {
     GraphDev g;
     // hot table (LDS): nodes ranked by pattern in-degree; edge_hot[k] = rank of indices[k] (HOT_NONE beyond the
@@ -366,8 +357,6 @@ struct PushParams {
     int32_t *sup;      // [slots][n]   candidate list (see cand_thr)
     uint32_t qcap;     // power of two
     int32_t max_pushes; // per-seed cap, see ST_RUNAWAY
-    int32_t prefetch_next;   // fetch the next passing entry's row data while the current one is pushed
-    int32_t watch;           // keep the pop batch's r values current in LDS (0: re-read them from HBM after every push)
     // outputs
     int32_t *raw;      // raw row arena, allocation order
     unsigned long long rawcap;
@@ -447,10 +436,7 @@ __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
     const uint32_t qmask = P.qcap - 1;
     const T omr = (T)P.one_minus_rho;
     const uint32_t K = HOT ? P.hotK : 0u;
-    unsigned char *lds_wave = hot_raw + (size_t)wave * ((size_t)K * sizeof(T) + watch_bytes<T>());
-    T *hot = reinterpret_cast<T *>(lds_wave);
-    int32_t *wkey = reinterpret_cast<int32_t *>(lds_wave + (size_t)K * sizeof(T));
-    T *wval = reinterpret_cast<T *>(lds_wave + (size_t)K * sizeof(T) + WATCH_SLOTS * sizeof(int32_t));
+    T *hot = reinterpret_cast<T *>(hot_raw) + (size_t)wave * K;
     uint32_t epoch = P.slot_epoch[slot];
 
     // Dynamic seed queue: lane 0 draws the next work item, the wave broadcasts it.  The
@@ -500,7 +486,6 @@ __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
             // s[:] = 0; r[:] = 0 for the on-chip nodes
             for (uint32_t i = lane; i < K; i += WAVE) hot[i] = T(0);
         }
-        for (int i = lane; i < WATCH_SLOTS; i += WAVE) wkey[i] = -1;       // no batch in flight yet
 
         uint32_t head = 0, tail = 0;       // ring counters (wave-uniform)
         int32_t nsup = 0;          // candidates
@@ -528,9 +513,7 @@ __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
 
         // ---- one push of node u (push.py:41-64) followed by the ordered enqueue of
         //      similarity.py:194-196 / :214-216.  `ru` is r[u] at pop time, `hu` u's hot rank, `du` its in_degree.
-        //      `pre`: the row data of the first step when the pop loop has fetched it ahead (NULL otherwise).
-        auto push = [&](int32_t u, uint32_t hu, uint32_t wu, T du, T ru, int64_t rb, int64_t re, bool do_enqueue,
-                        const RowStage<T, TILES> *pre) {
+        auto push = [&](int32_t u, uint32_t hu, T du, T ru, int64_t rb, int64_t re, bool do_enqueue) {
             T c;            // what every neighbour receives per unit of transition weight
             T r_self;       // r[u] right after the push bookkeeping (what a self-loop lane adds to)
             // u still on chip: this push is its first, so s[u] == r[u] == ru (ARCTE) or s[u] == 0 (PageRank
@@ -564,7 +547,6 @@ __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
                 nsup += g1;
                 nfirst += g1;
             }
-            if (wu != WATCH_NONE && lane == 0) wval[wu] = r_self;   // r[u] as the batch sees it from now on
             // The row is walked TILES x 64 edges at a time as a three-stage software pipeline: the row data (index,
             // weight, in_degree, hot rank) of step i+2 and the state gathers of step i+1 are in flight while step i
             // is added, stored and enqueued.  Legal because the targets of one row are distinct (CSR columns are
@@ -617,12 +599,6 @@ __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
                             store_lo(st + v, r_new, s_new);
                             if (!live) store_hi(st + v, dv, epoch);
                         }
-                        // is v waiting in the pop batch?  then its r there is this one now
-                        if (P.watch) for (uint32_t ws = watch_hash(v);; ws = (ws + 1) & (WATCH_SLOTS - 1)) {
-                            const int32_t wk = wkey[ws];
-                            if (wk == v) { wval[ws] = r_new; break; }
-                            if (wk == -1) break;
-                        }
                     }
                     if (VAR == 0) {
                         // Candidate list: every node whose s/in_degree has reached cand_thr, a lower bound of
@@ -654,7 +630,7 @@ __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
             };
             constexpr int64_t STEP = TILES * WAVE;
             if (re - rb > STEP) {
-                if (pre) Ra = *pre; else load_row(rb, Ra);
+                load_row(rb, Ra);
                 load_row(rb + STEP, Rb);
                 gather(Ra, Ea);
                 for (int64_t base = rb; base < re; base += STEP) {
@@ -668,7 +644,7 @@ __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
                 }
             } else if (re > rb) {
                 // a row that fits one step (most pushes, a minority of the edges): nothing to overlap
-                if (pre) Ra = *pre; else load_row(rb, Ra);
+                load_row(rb, Ra);
                 gather(Ra, Ea);
                 process(Ra, Ea);
             }
@@ -707,13 +683,13 @@ __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
             cand_thr = wave_min_real<T>(lb) * cand_margin<T>();
         }
         // (PageRank flavours: s is non-zero only at pushed nodes; the candidate list is the pushed nodes)
-        push(seed, HOT_NONE, WATCH_NONE, seed_d, T(1), seed_b, seed_e, true, nullptr);
+        push(seed, HOT_NONE, seed_d, T(1), seed_b, seed_e, true);
         if (VAR == 2) {
             // similarity.py:108-116: re-push the seed while it stays above the threshold, no enqueue
             while (ok) {
                 const T ru2 = st[seed].r;
                 if (!(ru2 / seed_d >= eps)) break;
-                push(seed, HOT_NONE, WATCH_NONE, seed_d, ru2, seed_b, seed_e, false, nullptr);
+                push(seed, HOT_NONE, seed_d, ru2, seed_b, seed_e, false);
             }
         }
 
@@ -726,10 +702,9 @@ __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
             const uint32_t bn = navail < (uint32_t)WAVE ? navail : (uint32_t)WAVE;
             const bool valid = (uint32_t)lane < bn;
             int32_t u_l = 0;
-            uint32_t h_l = HOT_NONE, w_l = WATCH_NONE;
+            uint32_t h_l = HOT_NONE;
             T r_l = T(0), d_l = T(1);
             int64_t rb_l = 0, re_l = 0;
-            for (int i = lane; i < WATCH_SLOTS; i += WAVE) wkey[i] = -1;
             if (valid) {
                 const QEntry e = q[(head + lane) & qmask];
                 u_l = e.v;
@@ -738,60 +713,41 @@ __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
                 r_l = read_r(u_l, h_l);       // queued nodes were deposited to in this epoch: live
                 rb_l = g.indptr[u_l];
                 re_l = g.indptr[u_l + 1];
-                // enter the node into the watch table (a node queued twice shares one slot)
-                for (uint32_t ws = watch_hash(u_l);; ws = (ws + 1) & (WATCH_SLOTS - 1)) {
-                    const int32_t old = atomicCAS(wkey + ws, -1, u_l);
-                    if (old == -1 || old == u_l) { w_l = ws; break; }
-                }
-                wval[w_l] = r_l;
             }
             head += bn;    // the batch lives in registers from here on
             int consumed = 0;
             bool pass = valid && (r_l / d_l >= eps);                                  // similarity.py:204
-            // Row data fetched ahead: while entry i is pushed, the first step of the row of the NEXT passing entry
-            // (as things stand before the push) is already on its way; if that entry is indeed the next one pushed
-            // -- the push may lift an earlier entry over the threshold instead -- its push starts with the data in
-            // registers.  Graph arrays only: nothing about the result depends on the guess.
-            RowStage<T, TILES> Rp, Rn;
-            int pre_lane = -1;
             for (;;) {
                 const uint64_t m = __ballot(pass && lane >= consumed);
                 if (m == 0) break;
                 const int i = __ffsll((unsigned long long)m) - 1;
-                const bool use_pre = pre_lane == i;
-                int next_lane = -1;
-                if (P.prefetch_next) {
-                    const uint64_t m2 = m & (m - 1);
-                    if (m2) {
-                        const int j = __ffsll((unsigned long long)m2) - 1;
-                        const int64_t rbj = shfl_i64(rb_l, j), rej = shfl_i64(re_l, j);
-                        if (rej > rbj) { load_row_at(rbj, rej, Rn); next_lane = j; }
-                    }
-                }
                 const int32_t u = __shfl(u_l, i, WAVE);
                 const uint32_t hu = (uint32_t)__shfl((int)h_l, i, WAVE);
-                const uint32_t wu = (uint32_t)__shfl((int)w_l, i, WAVE);
                 const T du = shfl_real<T>(d_l, i);
-                const T ru = shfl_real<T>(r_l, i);           // current: refreshed from the watch table after every push
                 consumed = i + 1;
+                // r of a passing entry can only have grown since it was read -- unless the node was pushed in
+                // between (the queue holds duplicates): read it again, it is this entry's pop time now
+                const T ru = read_r(u, hu);
+                if (!(ru / du >= eps)) {
+                    if (lane == i) pass = false;
+                    continue;
+                }
                 const int64_t rb = shfl_i64(rb_l, i);
                 const int64_t re = shfl_i64(re_l, i);
-                push(u, hu, wu, du, ru, rb, re, true, use_pre ? &Rp : nullptr);
+                push(u, hu, du, ru, rb, re, true);
                 if (VAR == 2) {
                     // similarity.py:136-144: re-push the same node while it stays above the threshold
                     while (ok) {
                         const T ru2 = st[u].r;
                         if (!(ru2 / du >= eps)) break;
-                        push(u, hu, wu, du, ru2, rb, re, false, nullptr);
+                        push(u, hu, du, ru2, rb, re, false);
                     }
                 }
                 if (!ok) break;
-                Rp = Rn;
-                pre_lane = next_lane;
-                // every test must see r at its pop time: the push has left the new r of every batch node it touched
-                // (and of u itself) in the watch table
-                if (valid && lane >= consumed) {
-                    r_l = P.watch ? wval[w_l] : read_r(u_l, h_l);     // (watch off: the A/B arm, a gather from HBM)
+                // re-test the entries that did not pass: the push may have lifted them over the threshold (a passing
+                // entry is re-read when its turn comes), so every test sees r at its pop time
+                if (valid && lane >= consumed && !pass) {
+                    r_l = read_r(u_l, h_l);
                     pass = r_l / d_l >= eps;
                 }
             }

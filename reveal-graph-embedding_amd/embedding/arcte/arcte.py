@@ -27,19 +27,13 @@ def calculate_epsilon_effective(rho, epsilon, seed_degree, neighbor_degrees, mea
     """
     Semi-automatic effective epsilon threshold calculation (reference arcte.py:26-50).
 
-    Evaluated by the same kernel arcte_worker uses, on a star graph whose hub carries `seed_degree`
-    and whose leaves carry `neighbor_degrees`.  rho and mean_degree are unused, as in the reference.
+    Evaluated by the same kernel arcte_worker uses (numpy's pairwise summation order for the mean, device log); no
+    context, no slots.  rho and mean_degree are unused, as in the reference.
     """
     nd = np.ascontiguousarray(neighbor_degrees, dtype=np.float64).reshape(-1)
-    m = nd.size
-    if m == 0:
+    if nd.size == 0:
         raise ValueError("zero-size array to reduction operation maximum which has no identity")
-    indptr = np.zeros(m + 2, dtype=np.int64)
-    indptr[1:] = m
-    indices = np.arange(1, m + 1, dtype=np.int32)
-    out_degree = np.concatenate([[float(seed_degree)], nd])
-    with _native.Context(indptr, indices, np.ones(m), out_degree, np.ones(m + 1), n_slots=4) as ctx:
-        return float(ctx.epsilon_effective(np.zeros(1, dtype=np.int64), epsilon)[0])
+    return _native.epsilon_effective_scalar(epsilon, seed_degree, nd)
 
 
 def _seed_matrix(n, seeds, colptr, rows):

@@ -1,0 +1,28 @@
+#!/bin/bash
+# Per-experiment evidence for the push kernel (run on the GPU box): for each launch shape, the kernel's duration
+# (rocprofv3 --kernel-trace --stats) and, in separate --pmc passes, the memory-side request counters.
+# Workload: bench.py --shards 8 (seed shard 0 of 8 of the 1M/50M graph, 81 434 seeds per launch).
+set -o pipefail
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+OUT=$R/gpurun_out/prof_exp
+rm -rf $OUT && mkdir -p $OUT
+ARGS="$R/bench.py --shards 8 --steps 2 --warmup 1 --cpu-seconds 0"
+python3 $R/bench.py --shards 8 --steps 1 --warmup 0 --cpu-seconds 0 > /dev/null 2>&1   # graph cache
+arm() {  # name, env assignments...
+  name=$1; shift
+  for kv in "$@"; do export "$kv"; done
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$name/trace -- python3 $ARGS > $OUT/$name.bench.json 2> $OUT/$name.trace.err
+  for pass in "TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_HIT_sum TCC_MISS_sum" "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM SQ_INSTS_LDS"; do
+    p=$(echo $pass | tr ' ' '_' | cut -c1-24)
+    rocprofv3 --pmc $pass --output-format csv -d $OUT/$name/pmc_$p -- python3 $ARGS > /dev/null 2> $OUT/$name.pmc_$p.err
+  done
+  for kv in "$@"; do unset "${kv%%=*}"; done
+  echo "arm $name done"
+}
+arm r1_shape_hot_off ARCTE_HIP_HOT=0 ARCTE_HIP_WAVES_PER_CU=8
+arm hot_w8 ARCTE_HIP_WAVES_PER_CU=8
+arm hot_w4_default
+arm hot_w4_tiles4 ARCTE_HIP_TILES=4
+python3 $R/tools/summarise_experiments.py $OUT > $OUT/summary.txt 2>&1
+cat $OUT/summary.txt
