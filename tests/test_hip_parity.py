@@ -397,3 +397,14 @@ def test_bench_two_ranks_gather_equals_reference_hash(tmp_path):
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and cfg["seeds_per_step"] == 63070
     assert cfg["gathered_rows_rank0"] == cfg["emitted_rows_all_ranks"] == int(z["nnz"]) - 100000 - 3554220
     assert cfg["merged_sha256"] == bytes(z["sha256"]).hex()
+
+
+def test_config0_ba20000_rho1e3_matches_reference_hash():
+    """BASELINE.json configs[0], stand-in no. 2: BA(20 000, 10), rho = 1e-3, eps = 1e-5 -- every seed, against the
+    SHA-256 of the reference's own 8-process run."""
+    from test_oracle_golden import _summary_hash, load_ba20000
+    z, a = load_ba20000()
+    f, digest = _summary_hash(arcte(a, float(z["rho"]), float(z["epsilon"]), 1))
+    assert f.nnz == int(z["nnz"])
+    assert np.array_equal(np.diff(sparse.csc_matrix(f[:, a.shape[0]:]).indptr), z["local_col_counts"])
+    assert np.array_equal(digest, z["sha256"])

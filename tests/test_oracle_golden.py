@@ -94,3 +94,31 @@ def test_config1_rmat_full_size():
     assert np.array_equal(np.frombuffer(h.digest(), dtype=np.uint8), z["sha256"])
     local = sparse.csc_matrix(f[:, 100000:])
     assert np.array_equal(np.diff(local.indptr), z["local_col_counts"])
+
+
+def _summary_hash(f):
+    import hashlib
+    f = sparse.csr_matrix(f)
+    f.sum_duplicates()
+    f.sort_indices()
+    h = hashlib.sha256()
+    h.update(f.indptr.astype(np.int64).tobytes())
+    h.update(f.indices.astype(np.int64).tobytes())
+    return f, np.frombuffer(h.digest(), dtype=np.uint8)
+
+
+def load_ba20000():
+    """BASELINE.json configs[0], stand-in no. 2: BA(20 000, 10) at rho = 1e-3, eps = 1e-5 as the
+    reference's own arcte() answered it (tests/golden/make_golden_ba20000.py)."""
+    z = np.load(os.path.join(GOLDEN, "ba20000_rho1e-3_summary.npz"))
+    n = z["adj_indptr"].size - 1
+    a = sparse.csr_matrix((np.ones(z["adj_indices"].size), z["adj_indices"], z["adj_indptr"]), shape=(n, n))
+    return z, a
+
+
+def test_oracle_config0_ba20000_rho1e3_matches_reference_hash():
+    z, a = load_ba20000()
+    f, digest = _summary_hash(oracle.arcte(a, float(z["rho"]), float(z["epsilon"]), oracle.lib().oracle_max_threads()))
+    assert f.nnz == int(z["nnz"])
+    assert np.array_equal(np.diff(sparse.csc_matrix(f[:, a.shape[0]:]).indptr), z["local_col_counts"])
+    assert np.array_equal(digest, z["sha256"])

@@ -14,7 +14,7 @@ def main():
         for path in glob.glob(os.path.join(out, arm, "trace", "**", "*kernel_stats.csv"), recursive=True):
             for r in csv.DictReader(open(path)):
                 if "k_arcte_seeds" in r["Name"]:
-                    rec["kernel"] = r["Name"].split("(")[0].replace("void (anonymous namespace)::", "")
+                    rec["kernel"] = r["Name"].replace("void (anonymous namespace)::", "").split("((anonymous")[0]
                     rec["ms_per_launch"] = float(r["AverageNs"]) / 1e6
                     rec["launches"] = int(r["Calls"])
         for path in glob.glob(os.path.join(out, arm, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
