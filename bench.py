@@ -293,7 +293,7 @@ def main():
                 "seeds_per_step": seeds_per_step,
                 "shards": args.shards,
                 "slots_per_gpu": info["slots"], "waves_per_cu": info["waves_per_cu"],
-                "hot_values_per_wave": info["hot_values_per_wave"],
+                "hot_values_per_wave": info["hot_values_per_wave"], "narrow_rows": info["narrow_rows"],
                 "kernel_source_id": kernel_source_id(),
                 "emitted_rows_rank0": int(total_rows), "emitted_rows_all_ranks": emitted_all, "merged_sha256": merged_sha,
                 "gathered_rows_rank0": int(gathered_rows),
@@ -304,8 +304,9 @@ def main():
                 "pcie_inclusive_seeds_per_s_rank0": shard.size / ((elapsed / max(args.steps, 1)) + fetch_ms * 1e-3),
             },
             "roofline": {
-                "bound": "hbm", "kernel": "k_arcte_seeds<0, %d, %s, %d, %s>" % (variant, "float" if args.float32 else "double", info["tiles"],
-                                                                "true" if info["hot_values_per_wave"] else "false"),
+                "bound": "hbm", "kernel": "k_arcte_seeds<0, %d, %s, %d, %s%s>" % (variant, "float" if args.float32 else "double", info["tiles"],
+                                                                  "true" if info["hot_values_per_wave"] else "false",
+                                                                  ", true" if info["narrow_rows"] and info["hot_values_per_wave"] else ""),
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic, "traffic_note": traffic_note,
                 "measured_stream_peak": {"read_GBps": stream_read, "copy_GBps": stream_copy,

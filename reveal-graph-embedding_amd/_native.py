@@ -310,11 +310,11 @@ class Context:
         return dict(eps_ms=float(t[0]), push_ms=float(t[1]), compact_ms=float(t[2]), call_ms=float(t[3]))
 
     def info(self):
-        i = np.zeros(8, dtype=np.int64)
+        i = np.zeros(10, dtype=np.int64)
         _check(lib().arcte_hip_info(self._h, i))
         return dict(slots=int(i[0]), queue_capacity=int(i[1]), device_bytes=int(i[2]), compute_units=int(i[3]),
                     waves_per_workgroup=int(i[4]), hot_values_per_wave=int(i[5]), tiles=int(i[6]),
-                    waves_per_cu=int(i[7]))
+                    waves_per_cu=int(i[7]), narrow_rows=int(i[8]))
 
     def launch_occupancy(self):
         """Workgroups of the propagation kernel per CU according to the runtime's occupancy query (diagnostic)."""

@@ -26,6 +26,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "arcte_hip.h"
@@ -147,6 +148,7 @@ struct arcte_hip_ctx {
     int waves_per_block = 1;     // wavefronts per workgroup of k_arcte_seeds
     int waves_per_cu = 0;        // resident wavefronts per CU the slot count was sized for
     int tiles = 2;               // 64-edge tiles per push iteration
+    int narrow = 0;              // uniform row weights + float32-exact in_degrees: the push streams 10 bytes per edge
     uint64_t seeds_since_clear = 0;
     std::vector<int32_t> row_len;   // host copy of the row lengths: the work order is heaviest seed first
     // per-run
@@ -285,6 +287,10 @@ int launch_seeds_v(arcte_hip_ctx *c, PushParams P, int64_t nwork)
     P.hotK = hot_values_per_wave(c, sizeof(T));
     const size_t lds = (size_t)wpb * P.hotK * sizeof(T);
     if (P.hotK == 0) return launch_with_lds(k_arcte_seeds<MODE, VAR, T, 2, false>, blocks, wpb * WAVE, lds, c->stream, P);
+    if constexpr (std::is_same<T, double>::value) {
+        if (c->narrow && c->tiles == 4) return launch_with_lds(k_arcte_seeds<MODE, VAR, T, 4, true, true>, blocks, wpb * WAVE, lds, c->stream, P);
+        if (c->narrow) return launch_with_lds(k_arcte_seeds<MODE, VAR, T, 2, true, true>, blocks, wpb * WAVE, lds, c->stream, P);
+    }
     if (c->tiles == 4) return launch_with_lds(k_arcte_seeds<MODE, VAR, T, 4, true>, blocks, wpb * WAVE, lds, c->stream, P);
     return launch_with_lds(k_arcte_seeds<MODE, VAR, T, 2, true>, blocks, wpb * WAVE, lds, c->stream, P);
 }
@@ -300,6 +306,7 @@ int launch_centrality(arcte_hip_ctx *c, PushParams P, int64_t nwork)
     P.hotK = hot_values_per_wave(c, sizeof(double));
     const size_t lds = (size_t)wpb * P.hotK * sizeof(double);
     if (P.hotK == 0) return launch_with_lds(k_arcte_seeds<2, 0, double, 2, false>, blocks, wpb * WAVE, lds, c->stream, P);
+    if (c->narrow) return launch_with_lds(k_arcte_seeds<2, 0, double, 2, true, true>, blocks, wpb * WAVE, lds, c->stream, P);
     return launch_with_lds(k_arcte_seeds<2, 0, double, 2, true>, blocks, wpb * WAVE, lds, c->stream, P);
 }
 
@@ -317,7 +324,7 @@ int prepare_precision(arcte_hip_ctx *c)
 {
     if (c->float32 && !c->data_f.p) {
         HIP_TRY(c->data_f.alloc(c->nnz));
-        HIP_TRY(c->edge_in_degree_f.alloc(c->nnz));
+        if (!c->edge_in_degree_f.p) HIP_TRY(c->edge_in_degree_f.alloc(c->nnz));
         HIP_TRY(c->in_degree_f.alloc(c->n));
         const int tb = 256;
         if (c->nnz) {
@@ -434,6 +441,30 @@ int ctx_finish(arcte_hip_ctx *c, int64_t n_slots, int64_t queue_capacity)
         hipLaunchKernelGGL(k_edge_in_degree, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, c->stream, c->indices.p,
                            c->in_degree.p, c->edge_in_degree.p, nnz);
         HIP_TRY(hipGetLastError());
+    }
+    // ---- narrow rows?  (unweighted graphs: one weight per row; integer degrees: exact in float32)
+    c->narrow = 0;
+    if (nnz && env_int("ARCTE_HIP_NARROW", 1)) {
+        DevBuf<int32_t> flags;
+        int32_t fl[2] = {1, 1};
+        int rn = [&]() -> int {
+            HIP_TRY(flags.alloc(2));
+            HIP_TRY(hipMemsetAsync(flags.p, 0, 2 * sizeof(int32_t), c->stream));
+            hipLaunchKernelGGL(k_check_narrow, dim3((unsigned)((n + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK)), dim3(BLOCK), 0, c->stream, c->indptr.p,
+                               c->data.p, c->in_degree.p, n, flags.p);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpyAsync(fl, flags.p, sizeof(fl), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            return 0;
+        }();
+        flags.release();
+        if (rn) return rn;
+        if (!fl[0] && !fl[1]) {
+            HIP_TRY(c->edge_in_degree_f.alloc(nnz));
+            hipLaunchKernelGGL(k_to_float, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, c->stream, c->edge_in_degree.p, c->edge_in_degree_f.p, nnz);
+            HIP_TRY(hipGetLastError());
+            c->narrow = 1;
+        }
     }
     // ---- hot table: the ranks stream with the rows.  All on the device; the host never sees the ranking.
     {
@@ -557,7 +588,7 @@ int transition_on_device(arcte_hip_ctx *c)
 
 extern "C" {
 
-int arcte_hip_abi_version(void) { return 6; }
+int arcte_hip_abi_version(void) { return 7; }
 
 const char *arcte_hip_last_error(void) { return g_err.c_str(); }
 
@@ -2097,7 +2128,7 @@ int arcte_hip_launch_occupancy(arcte_hip_ctx *c, int *workgroups_per_cu)
     return 0;
 }
 
-int arcte_hip_info(arcte_hip_ctx *c, int64_t info[8])
+int arcte_hip_info(arcte_hip_ctx *c, int64_t info[10])
 {
     if (!c || !info) return fail(ARCTE_HIP_EINVAL, "bad argument");
     info[0] = c->slots;
@@ -2108,6 +2139,8 @@ int arcte_hip_info(arcte_hip_ctx *c, int64_t info[8])
     info[5] = hot_values_per_wave(c, c->float32 ? sizeof(float) : sizeof(double));
     info[6] = c->tiles;
     info[7] = c->waves_per_cu;
+    info[8] = (c->narrow && !c->float32) ? 1 : 0;
+    info[9] = 0;
     return 0;
 }
 

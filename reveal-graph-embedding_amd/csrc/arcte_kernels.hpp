@@ -421,7 +421,10 @@ template <typename T, int TILES> struct EntStage {
 // a node that IS pushed -- and the seed -- moves to the dense HBM state and leaves the sentinel behind.  Every
 // deposit to an on-chip node is an LDS read-modify-write instead of a random HBM one: with 2 560-5 120 values per
 // wavefront that is 20-30 % of the traversed edges of the 1M/50M graph (tools/hot_share.py).
-template <int MODE, int VAR, typename T, int TILES, bool HOT>
+// NARROW (float64 only): every row's transition weights are one and the same number (an unweighted graph: 1/out_degree)
+// and every in_degree is exactly representable in float32, so a push streams 10 bytes per edge (index, float in_degree,
+// hot rank) instead of 22 -- the weight comes from the row's first entry, the in_degree widens back to the same double.
+template <int MODE, int VAR, typename T, int TILES, bool HOT, bool NARROW = false>
 __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char hot_raw[];
@@ -500,13 +503,15 @@ __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
         // row's last edge, the seed's own state entry: lines that are in cache anyway).  Loads under an
         // exec-masked branch would leave the number of outstanding loads unknown to the compiler, which then
         // waits for ALL of them (vmcnt(0)) before the first use and serialises the pipeline.
-        auto load_row_at = [&](int64_t base, int64_t re, RowStage<T, TILES> &R) {
+        auto load_row_at = [&](int64_t base, int64_t re, T w_row, RowStage<T, TILES> &R) {
 #pragma unroll
             for (int t = 0; t < TILES; t++) {
                 const int64_t k = base + t * WAVE + lane;
                 R.a[t] = k < re;
                 const int64_t kk = R.a[t] ? k : re - 1;
-                R.v[t] = g.indices[kk]; R.w[t] = gv.data[kk]; R.d[t] = gv.edge_in_degree[kk];
+                R.v[t] = g.indices[kk];
+                if (NARROW) { R.w[t] = w_row; R.d[t] = (T)g.edge_in_degree_f[kk]; }
+                else { R.w[t] = gv.data[kk]; R.d[t] = gv.edge_in_degree[kk]; }
                 R.hh[t] = HOT ? (uint32_t)P.edge_hot[kk] : HOT_NONE;
             }
         };
@@ -554,7 +559,8 @@ __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
             // pushes program order holds (the next push's gathers are issued after this push's last store).
             RowStage<T, TILES> Ra, Rb, Rc;
             EntStage<T, TILES> Ea, Eb;
-            auto load_row = [&](int64_t base, RowStage<T, TILES> &R) { load_row_at(base, re, R); };
+            const T w_row = (NARROW && re > rb) ? gv.data[rb] : T(0);
+            auto load_row = [&](int64_t base, RowStage<T, TILES> &R) { load_row_at(base, re, w_row, R); };
             auto gather = [&](const RowStage<T, TILES> &R, EntStage<T, TILES> &E) {
 #pragma unroll
                 for (int t = 0; t < TILES; t++) {
@@ -1025,6 +1031,24 @@ __global__ void k_edge_hot(const int32_t *indices, const uint16_t *node_hot, uin
 {
     int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k < nnz) edge_hot[k] = node_hot[indices[k]];
+}
+
+// May the propagation stream the narrow rows (see k_arcte_seeds)?  flags[0]: some row holds two different weights;
+// flags[1]: some in_degree does not survive the round trip through float32.  One wavefront per row.
+__global__ __launch_bounds__(BLOCK) void k_check_narrow(const int64_t *indptr, const double *data, const double *in_degree, int64_t n,
+                                                        int32_t *flags)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const int64_t b = indptr[i], e = indptr[i + 1];
+    bool differs = false;
+    if (e > b) {
+        const double w0 = data[b];
+        for (int64_t k = b + lane; k < e; k += WAVE) differs |= (__double_as_longlong(data[k]) != __double_as_longlong(w0));
+    }
+    if (differs) flags[0] = 1;
+    if (lane == 0 && (double)(float)in_degree[i] != in_degree[i]) flags[1] = 1;
 }
 
 // in_degree[indices[k]] for every stored edge

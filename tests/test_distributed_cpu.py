@@ -139,3 +139,35 @@ def test_sharded_arcte_and_centrality(tmp_path, world, name):
     for c in cs[1:]:
         assert np.array_equal(c, cs[0])
     np.testing.assert_allclose(cs[0], g["centrality"], rtol=1e-13, atol=0)
+
+
+def _hip_centrality_worker(rank, world, port, name, out_path):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from reveal_graph_embedding_amd.distributed import arcte_and_centrality_distributed
+    from test_centrality_weighting_cpu import load_centrality
+    g = load_centrality(name)
+    f, c = arcte_and_centrality_distributed(g["adjacency"], float(g["rho"]), float(g["epsilon"]), device=0)
+    if rank == 0:
+        f.sort_indices()
+        np.savez(out_path, indptr=f.indptr, indices=f.indices, data=f.data, shape=np.array(f.shape), centrality=c)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_sharded_arcte_and_centrality_with_hip_compute_and_gloo_transport(tmp_path):
+    """Two ranks on the one GPU: node blocks, partial centralities from the HIP path, the all-reduce and the gather over
+    gloo, feature normalisation on the GPU -- everything of the sharded centrality driver except the RCCL transport."""
+    import scipy.sparse as sparse
+    from test_centrality_weighting_cpu import assert_close_sparse, load_centrality
+    out = str(tmp_path / "f.npz")
+    mp.spawn(_hip_centrality_worker, args=(2, _free_port(), "rmat2000", out), nprocs=2, join=True)
+    g = load_centrality("rmat2000")
+    z = np.load(out)
+    f = sparse.csr_matrix((z["data"], z["indices"], z["indptr"]), shape=tuple(z["shape"]))
+    assert_close_sparse(f, g["features"], 1e-12)
+    np.testing.assert_allclose(z["centrality"], g["centrality"], rtol=1e-13, atol=0)

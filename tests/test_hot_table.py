@@ -83,3 +83,21 @@ def test_duplicate_columns_are_rejected():
     with pytest.raises(_native.ArcteHipError) as e:
         _native.Context(indptr, indices, np.ones(5), np.ones(3), np.ones(3))
     assert e.value.code == -1 and "twice" in str(e.value)
+
+
+@pytest.mark.parametrize("variant", FLAVOURS)
+def test_narrow_rows_are_invisible(variant, monkeypatch):
+    """Unweighted graphs stream 10 bytes per edge (one weight per row, float32 in_degrees that widen back exactly);
+    weighted ones cannot.  Same results either way."""
+    from reveal_graph_embedding_amd import _native
+    for name, expect in (("ba300", 1), ("rmat2000", 1), ("selfloop", 1), ("weighted", 0)):
+        g = load_golden(name)
+        w = g["w"]
+        with _native.Context(w.indptr, w.indices, w.data, g["out_degree"], g["in_degree"]) as ctx:
+            assert ctx.info()["narrow_rows"] == expect, name
+        monkeypatch.setenv("ARCTE_HIP_NARROW", "0")
+        ref = run(g, -1, variant, monkeypatch)
+        monkeypatch.setenv("ARCTE_HIP_NARROW", "1")
+        got = run(g, -1, variant, monkeypatch)
+        assert np.array_equal(got[0], ref[0]) and np.array_equal(got[2], ref[2]) and got[3] == ref[3], name
+        assert np.array_equal(sorted_rows(got[0], got[1]), sorted_rows(ref[0], ref[1])), name

@@ -5,18 +5,21 @@ import numpy as np
 sys.path.insert(0, ".")
 from oracle import oracle
 from reveal_graph_embedding_amd import _native
-from reveal_graph_embedding_amd.synthetic import rmat_graph
-from reveal_graph_embedding_amd.eps_randomwalk.transition import get_natural_random_walk_matrix
-from reveal_graph_embedding_amd.embedding.arcte.arcte import seed_nodes
+import scipy.sparse as sparse
+sys.path.insert(0, "tools")
+from hot_sweep import load_graph
 
 variant = int(sys.argv[1]) if len(sys.argv) > 1 else 0      # 0 ARCTE, 1 PageRank, 2 lazy PageRank
 stride = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-A = rmat_graph(1000000, 50000000, 0)
-w, od, idg = get_natural_random_walk_matrix(A)
-seeds = np.sort(seed_nodes(A))[::stride]
-print("seeds", seeds.size, flush=True)
+A = load_graph(1000000, 50000000)
 t = time.time()
-with _native.Context(w.indptr, w.indices, w.data, od, idg) as ctx:
+# the graph is prepared ON THE DEVICE (transition matrix, degrees, seed list) and handed to the oracle from there:
+# the oracle's own preparation of this graph is the scipy path the device version is tested against elsewhere
+with _native.Context.from_adjacency(A.indptr, A.indices, A.data) as ctx:
+    seeds = np.sort(ctx.seed_list())[::stride]
+    print("seeds", seeds.size, "hot values per wavefront", ctx.info()["hot_values_per_wave"], flush=True)
+    indptr, indices, data, od, idg = ctx.transition()
+    w = sparse.csr_matrix((data, indices, indptr), shape=A.shape)
     ctx.run_seeds(seeds, (0.1 * 0.5) / (1 - 0.5 * 0.1) if variant == 2 else 0.1, 1e-5, variant=variant)
     colptr, rows, nop = ctx.fetch(want_nop=True)
     st = ctx.stats()
