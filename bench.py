@@ -294,6 +294,7 @@ def main():
                 "shards": args.shards,
                 "slots_per_gpu": info["slots"], "waves_per_cu": info["waves_per_cu"],
                 "hot_values_per_wave": info["hot_values_per_wave"], "narrow_rows": info["narrow_rows"],
+                "warm_end_rank": info["warm_end_rank"],
                 "kernel_source_id": kernel_source_id(),
                 "emitted_rows_rank0": int(total_rows), "emitted_rows_all_ranks": emitted_all, "merged_sha256": merged_sha,
                 "gathered_rows_rank0": int(gathered_rows),

@@ -314,7 +314,7 @@ class Context:
         _check(lib().arcte_hip_info(self._h, i))
         return dict(slots=int(i[0]), queue_capacity=int(i[1]), device_bytes=int(i[2]), compute_units=int(i[3]),
                     waves_per_workgroup=int(i[4]), hot_values_per_wave=int(i[5]), tiles=int(i[6]),
-                    waves_per_cu=int(i[7]), narrow_rows=int(i[8]))
+                    waves_per_cu=int(i[7]), narrow_rows=int(i[8]), warm_end_rank=int(i[9]))
 
     def launch_occupancy(self):
         """Workgroups of the propagation kernel per CU according to the runtime's occupancy query (diagnostic)."""

@@ -138,6 +138,9 @@ struct arcte_hip_ctx {
     DevBuf<int32_t> sup;
     // hot table (LDS-resident state of the highest-degree nodes) and the launch shape that goes with it
     DevBuf<uint16_t> node_hot, edge_hot;
+    DevBuf<char> warm;           // [slots][warm_n] {value, tag} pairs (16 bytes each): the ranks behind the LDS table
+    int64_t warm_n = 0;          // entries per slot
+    uint32_t warm_k2 = 0;        // ranks below this have a warm entry (0: off)
     int64_t hot_ranked = 0;      // nodes that carry a rank (<= HOT_NONE)
     // arcte_and_centrality (arcte.pyx:125-241)
     DevBuf<uint64_t> contrib_key;
@@ -187,7 +190,7 @@ struct arcte_hip_ctx {
     size_t device_bytes() const
     {
         return indptr.bytes() + indices.bytes() + data.bytes() + out_degree.bytes() + in_degree.bytes() + edge_in_degree.bytes() + data_f.bytes() + in_degree_f.bytes() + edge_in_degree_f.bytes() + state.bytes() + slot_epoch.bytes() +
-               node_hot.bytes() + edge_hot.bytes() +
+               node_hot.bytes() + edge_hot.bytes() + warm.bytes() +
                queue.bytes() + sup.bytes() + seeds_d.bytes() + work_pos.bytes() + out_cnt.bytes() + status.bytes() +
                nop_d.bytes() + eps_d.bytes() + out_off.bytes() + dst_off.bytes() + raw.bytes() + rows_final.bytes();
     }
@@ -201,6 +204,15 @@ int alloc_slots(arcte_hip_ctx *c, int64_t slots, uint32_t qcap)
     HIP_TRY(c->slot_epoch.alloc((size_t)slots));
     HIP_TRY(c->sup.alloc((size_t)slots * c->n));
     HIP_TRY(c->queue.alloc((size_t)slots * qcap));
+    // warm table: one entry per rank in [0, warm_k2) per slot (the first hotK of them lie unused under the LDS table:
+    // the LDS share depends on the arithmetic type, the allocation does not)
+    c->warm.release();
+    c->warm_n = 0;
+    if (c->warm_k2 > 0) {
+        c->warm_n = c->warm_k2;
+        HIP_TRY(c->warm.alloc((size_t)slots * c->warm_n * 16));
+        HIP_TRY(hipMemsetAsync(c->warm.p, 0, c->warm.bytes(), c->stream));
+    }
     HIP_TRY(hipMemsetAsync(c->state.p, 0, c->state.bytes(), c->stream));
     HIP_TRY(hipMemsetAsync(c->slot_epoch.p, 0, c->slot_epoch.bytes(), c->stream));
     c->seeds_since_clear = 0;
@@ -277,6 +289,9 @@ int launch_seeds_v(arcte_hip_ctx *c, PushParams P, int64_t nwork)
     P.edge_hot = c->edge_hot.p;
     P.node_hot = c->node_hot.p;
     P.hotK = 0;
+    P.warm = (void *)c->warm.p;
+    P.warmK2 = c->warm_k2;
+    P.warmN = (uint32_t)c->warm_n;
     if (MODE == 1) {
         // works on the dense vectors the host placed in slot 0: exactly one wavefront may run, all state in HBM
         return launch_with_lds(k_arcte_seeds<MODE, VAR, T, 2, false>, 1, WAVE, 0, c->stream, P);
@@ -300,6 +315,9 @@ int launch_centrality(arcte_hip_ctx *c, PushParams P, int64_t nwork)
 {
     P.edge_hot = c->edge_hot.p;
     P.node_hot = c->node_hot.p;
+    P.warm = (void *)c->warm.p;
+    P.warmK2 = c->warm_k2;
+    P.warmN = (uint32_t)c->warm_n;
     const int wpb = c->waves_per_block;
     const int64_t waves = std::min<int64_t>(c->slots, std::max<int64_t>(nwork, 1));
     const int blocks = (int)((waves + wpb - 1) / wpb);
@@ -336,6 +354,7 @@ int prepare_precision(arcte_hip_ctx *c)
         HIP_TRY(hipGetLastError());
     }
     if (c->state_is_f32 != c->float32) {
+        if (c->warm.p) HIP_TRY(hipMemsetAsync(c->warm.p, 0, c->warm.bytes(), c->stream));
         HIP_TRY(hipMemsetAsync(c->state.p, 0, c->state.bytes(), c->stream));
         HIP_TRY(hipMemsetAsync(c->slot_epoch.p, 0, c->slot_epoch.bytes(), c->stream));
         c->seeds_since_clear = 0;
@@ -485,6 +504,11 @@ int ctx_finish(arcte_hip_ctx *c, int64_t n_slots, int64_t queue_capacity)
     // ---- launch shape.  The propagation kernel is bound by the chip's random-access rate into the per-slot HBM
     //      state, and the LDS-resident hot table takes 20-40 % of those accesses away -- the more the fewer
     //      wavefronts share a CU's LDS, while fewer wavefronts keep fewer accesses in flight.
+    // warm table: the ranks behind the LDS table keep their one value in a compact per-slot array (A/B on the 1M/50M
+    // graph: 110.3 -> 105.6 ms per 81 434 seeds at 4 wavefronts per CU, 115.9 -> 105.6 at 8; the same within 1.5 % for an
+    // end rank of 16 384, 32 768 or 65 535, so the middle one: 0.5 MB per slot)
+    c->warm_k2 = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(env_int("ARCTE_HIP_WARM", 32768), c->hot_ranked));
+    if (env_int("ARCTE_HIP_HOT", -1) == 0) c->warm_k2 = 0;
     c->waves_per_block = std::max(1, std::min(env_int("ARCTE_HIP_WAVES_PER_BLOCK", 1), WAVES_PER_BLOCK));
     c->tiles = env_int("ARCTE_HIP_TILES", 2) == 4 ? 4 : 2;
     const int wpb = c->waves_per_block;
@@ -495,7 +519,7 @@ int ctx_finish(arcte_hip_ctx *c, int64_t n_slots, int64_t queue_capacity)
         // keep the slot scratch within a fixed share of the device
         size_t free_b = 0, total_b = 0;
         HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-        size_t per_slot = (size_t)n * (sizeof(Entry) + sizeof(int32_t)) + (size_t)default_queue_capacity(n) * sizeof(QEntry);
+        size_t per_slot = (size_t)n * (sizeof(Entry) + sizeof(int32_t)) + (size_t)default_queue_capacity(n) * sizeof(QEntry) + (size_t)c->warm_k2 * 16;
         while (slots > c->cus && (size_t)slots * per_slot > free_b / 4 * 3) slots -= c->cus / 2;
     }
     slots = std::max<int64_t>(wpb, (slots + wpb - 1) / wpb * wpb);
@@ -836,7 +860,7 @@ int arcte_hip_destroy(arcte_hip_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     c->indptr.release(); c->indices.release(); c->data.release(); c->out_degree.release(); c->in_degree.release();
-    c->state.release(); c->slot_epoch.release(); c->contrib_key.release(); c->contrib_val.release(); c->centrality.release(); c->ranked_ids.release(); c->node_hot.release(); c->edge_hot.release(); c->edge_in_degree.release(); c->data_f.release(); c->in_degree_f.release(); c->edge_in_degree_f.release(); c->queue.release(); c->sup.release();
+    c->state.release(); c->slot_epoch.release(); c->warm.release(); c->contrib_key.release(); c->contrib_val.release(); c->centrality.release(); c->ranked_ids.release(); c->node_hot.release(); c->edge_hot.release(); c->edge_in_degree.release(); c->data_f.release(); c->in_degree_f.release(); c->edge_in_degree_f.release(); c->queue.release(); c->sup.release();
     c->seeds_d.release(); c->work_pos.release(); c->out_cnt.release(); c->status.release(); c->nop_d.release();
     c->eps_d.release(); c->out_off.release(); c->dst_off.release(); c->counters.release();
     c->raw.release(); c->rows_final.release(); c->sort_keys.release(); c->sort_iota.release(); c->sort_temp.release(); c->eps_big_pos.release(); c->sort_keys_in.release();
@@ -972,6 +996,7 @@ static int run_seeds_impl(arcte_hip_ctx *c, const int64_t *seeds, int64_t nseeds
     // epochs are 32-bit and advance by one per seed and slot: clear long before any slot can wrap
     c->seeds_since_clear += (uint64_t)nseeds;
     if (c->seeds_since_clear > (1ull << 31)) {
+        if (c->warm.p) HIP_TRY(hipMemsetAsync(c->warm.p, 0, c->warm.bytes(), c->stream));
         HIP_TRY(hipMemsetAsync(c->state.p, 0, c->state.bytes(), c->stream));
         HIP_TRY(hipMemsetAsync(c->slot_epoch.p, 0, c->slot_epoch.bytes(), c->stream));
         c->seeds_since_clear = (uint64_t)nseeds;
@@ -2140,7 +2165,7 @@ int arcte_hip_info(arcte_hip_ctx *c, int64_t info[10])
     info[6] = c->tiles;
     info[7] = c->waves_per_cu;
     info[8] = (c->narrow && !c->float32) ? 1 : 0;
-    info[9] = 0;
+    info[9] = c->warm_k2;
     return 0;
 }
 

@@ -334,6 +334,23 @@ template <> __device__ __forceinline__ float hot_moved<float>() { return __uint_
 __device__ __forceinline__ bool is_moved(double x) { return __double_as_longlong(x) == 0x7FF8DEAD0000BEEFll; }
 __device__ __forceinline__ bool is_moved(float x) { return __float_as_uint(x) == 0x7FC0BEEFu; }
 
+// Warm table (HBM, one compact array per slot): the nodes ranked [hotK, warmK2) -- behind the LDS table in the same
+// degree order.  One {value, epoch tag} pair per node (two T-sized words: 16 bytes in float64), with the LDS table's
+// rule: the value stands for r == s until the node is pushed, a pushed node moves to the dense entry and leaves the
+// sentinel.  Nothing else is different from the dense state except the ADDRESS: a slot's warm nodes sit in
+// (warmK2 - hotK) * 16 bytes instead of being strewn over its 32 n bytes, so the lines the chip's last-level cache
+// keeps for a slot are lines the next deposits hit again (tools/rmw_wall2.hip: the same read-modify-write runs at
+// 22-27 G/s on 1-0.5 GB of private tables against 18.6 G/s on the dense layout).
+template <typename T> struct WarmT { T x; T tag; };
+__device__ __forceinline__ double warm_tag(uint32_t epoch, double) { return __longlong_as_double((long long)(uint64_t)epoch); }
+__device__ __forceinline__ float warm_tag(uint32_t epoch, float) { return __uint_as_float(epoch); }
+__device__ __forceinline__ bool warm_live(double tag, uint32_t epoch) { return (uint64_t)__double_as_longlong(tag) == (uint64_t)epoch; }
+__device__ __forceinline__ bool warm_live(float tag, uint32_t epoch) { return __float_as_uint(tag) == epoch; }
+__device__ __forceinline__ WarmT<double> load_warm(const WarmT<double> *e) { double2 t = *reinterpret_cast<const double2 *>(e); return {t.x, t.y}; }
+__device__ __forceinline__ WarmT<float> load_warm(const WarmT<float> *e) { float2 t = *reinterpret_cast<const float2 *>(e); return {t.x, t.y}; }
+__device__ __forceinline__ void store_warm(WarmT<double> *e, double x, uint32_t epoch) { *reinterpret_cast<double2 *>(e) = make_double2(x, warm_tag(epoch, 0.0)); }
+__device__ __forceinline__ void store_warm(WarmT<float> *e, float x, uint32_t epoch) { *reinterpret_cast<float2 *>(e) = make_float2(x, warm_tag(epoch, 0.0f)); }
+
 struct PushParams {
     GraphDev g;
     // hot table (LDS): nodes ranked by pattern in-degree; edge_hot[k] = rank of indices[k] (HOT_NONE beyond the
@@ -341,6 +358,9 @@ struct PushParams {
     const uint16_t *edge_hot;
     const uint16_t *node_hot;
     uint32_t hotK;
+    void *warm;        // [slots][warmN] WarmT<T>, indexed by rank; ranks [hotK, warmK2) are in use
+    uint32_t warmK2;   // <= hotK switches the warm table off
+    uint32_t warmN;    // entries per slot
     // work list
     const int32_t *work_pos;   // positions into seeds/eps/out arrays for this launch (NULL = identity)
     int64_t nwork;
@@ -406,6 +426,7 @@ template <typename T, int TILES> struct EntStage {
     HiT<T> h[TILES];
     T x[TILES];
     bool chip[TILES];
+    bool warm[TILES];
 };
 
 // MODE 0: full arcte_worker body (extract).  MODE 1: similarity slice only on the dense vectors the
@@ -440,6 +461,8 @@ __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
     const T omr = (T)P.one_minus_rho;
     const uint32_t K = HOT ? P.hotK : 0u;
     T *hot = reinterpret_cast<T *>(hot_raw) + (size_t)wave * K;
+    const uint32_t K2 = (HOT && P.warmK2 > K) ? P.warmK2 : K;          // warm ranks: [K, K2)
+    WarmT<T> *__restrict__ wm = reinterpret_cast<WarmT<T> *>(P.warm) + slot * (int64_t)P.warmN;   // indexed by rank
     uint32_t epoch = P.slot_epoch[slot];
 
     // Dynamic seed queue: lane 0 draws the next work item, the wave broadcasts it.  The
@@ -457,6 +480,9 @@ __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
         if (HOT && h < K) {
             const T x = hot[h];
             if (!is_moved(x)) return x;
+        } else if (HOT && h < K2) {
+            const WarmT<T> e = load_warm(wm + h);
+            if (warm_live(e.tag, epoch) && !is_moved(e.x)) return e.x;
         }
         return st[u].r;
     };
@@ -531,6 +557,15 @@ __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
                     store_lo(st + u, ru, (VAR == 0) ? ru : T(0));
                     store_hi(st + u, du, epoch);
                 }
+            } else if (HOT && hu < K2) {
+                // the same for a node of the warm table (u was deposited to in this epoch: its warm entry is live)
+                const WarmT<T> e = load_warm(wm + hu);
+                on_chip = warm_live(e.tag, epoch) && !is_moved(e.x);
+                if (on_chip && lane == 0) {
+                    store_warm(wm + hu, hot_moved<T>(), epoch);
+                    store_lo(st + u, ru, (VAR == 0) ? ru : T(0));
+                    store_hi(st + u, du, epoch);
+                }
             }
             if (VAR == 0) {
                 c = omr * ru;                                    // push.py:56
@@ -564,13 +599,32 @@ __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
             auto gather = [&](const RowStage<T, TILES> &R, EntStage<T, TILES> &E) {
 #pragma unroll
                 for (int t = 0; t < TILES; t++) {
-                    // nodes without a place in the table go to HBM at once, the others after a look at the table
-                    const bool cold = R.a[t] && !(HOT && R.hh[t] < K);
+                    // nodes without a place in the LDS table go to HBM at once (warm table or dense state), the others
+                    // after a look at the table
+                    const bool in_lds = HOT && R.hh[t] < K;
+                    const bool in_warm = HOT && !in_lds && R.hh[t] < K2;
+                    const bool cold = R.a[t] && !in_lds && !in_warm;
                     const EntryT<T> *e = cold ? st + R.v[t] : st + seed;
-                    E.l[t] = load_lo(e);
+                    // (a warm entry has the size of an entry's first half: one load serves either)
+                    const void *first = (R.a[t] && in_warm) ? (const void *)(wm + R.hh[t]) : (const void *)e;
+                    E.l[t] = load_lo(reinterpret_cast<const EntryT<T> *>(first));
                     E.h[t] = load_hi(e);
                     E.chip[t] = false;
+                    E.warm[t] = false;
                     E.x[t] = T(0);
+                }
+                if (HOT && K2 > K) {
+#pragma unroll
+                    for (int t = 0; t < TILES; t++) {
+                        if (R.a[t] && R.hh[t] >= K && R.hh[t] < K2) {
+                            // {value, tag} arrived as (lo.r, lo.s); a moved node is fetched from the dense state
+                            const bool live = warm_live(E.l[t].s, epoch);
+                            const bool moved = live && is_moved(E.l[t].r);
+                            E.warm[t] = !moved;
+                            E.x[t] = live ? E.l[t].r : T(0);
+                            if (moved) { E.l[t] = load_lo(st + R.v[t]); E.h[t] = load_hi(st + R.v[t]); }
+                        }
+                    }
                 }
                 if (HOT) {
 #pragma unroll
@@ -587,7 +641,8 @@ __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
 #pragma unroll
                 for (int t = 0; t < TILES; t++) {
                     const bool act = R.a[t];
-                    const bool chip = HOT && E.chip[t];
+                    const bool warm = HOT && E.warm[t];
+                    const bool chip = (HOT && E.chip[t]) || warm;        // one value stands for r == s
                     const int32_t v = R.v[t];
                     const T w = R.w[t];
                     const T dv = R.d[t];
@@ -600,7 +655,8 @@ __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
                     const T r_new = r_old + p;                          // push.py:64
                     const T s_new = (VAR == 0) ? s_old + p : s_old;     // push.py:63 (ARCTE only)
                     if (act) {
-                        if (chip) hot[R.hh[t]] = r_new;                 // == s_new for ARCTE; s stays 0 otherwise
+                        if (warm) store_warm(wm + R.hh[t], r_new, epoch);
+                        else if (chip) hot[R.hh[t]] = r_new;            // == s_new for ARCTE; s stays 0 otherwise
                         else {
                             store_lo(st + v, r_new, s_new);
                             if (!live) store_hi(st + v, dv, epoch);
@@ -671,6 +727,7 @@ __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
             if (HOT) {
                 const uint32_t hs = P.node_hot[seed];
                 if (hs < K) hot[hs] = hot_moved<T>();              // the seed's state is the HBM entry just written
+                else if (hs < K2) store_warm(wm + hs, hot_moved<T>(), epoch);
             }
         }
         nsup = (VAR == 0) ? 1 : 0;
@@ -781,6 +838,11 @@ __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
                         const T x = hot[hv];
                         chip = !is_moved(x);
                         if (chip) sv = (VAR == 0) ? x : T(0);
+                    } else if (hv < K2) {
+                        const WarmT<T> e = load_warm(wm + hv);
+                        const bool live = warm_live(e.tag, epoch);
+                        chip = !(live && is_moved(e.x));         // never touched (s = 0) or one value for r == s
+                        if (chip) sv = (live && VAR == 0) ? e.x : T(0);
                     }
                 }
                 if (!chip) {
@@ -830,6 +892,11 @@ __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
                                 chip = !is_moved(x);
                                 // (candidates of the PageRank flavours were pushed, so they are never on chip)
                                 if (chip) { sv = (VAR == 0) ? x : T(0); dv = gv.in_degree[v]; }
+                            } else if (hv < K2) {
+                                const WarmT<T> e = load_warm(wm + hv);
+                                const bool live = warm_live(e.tag, epoch);
+                                chip = !(live && is_moved(e.x));
+                                if (chip) { sv = (live && VAR == 0) ? e.x : T(0); dv = gv.in_degree[v]; }
                             }
                         }
                         if (!chip) { sv = st[v].s; dv = st[v].d; }

@@ -16,9 +16,13 @@ GRAPHS = ["ba300", "grid25", "corner", "weighted", "selfloop", "directed", "rmat
 FLAVOURS = [oracle.ARCTE, oracle.PAGERANK, oracle.LAZY_PAGERANK]
 
 
-def run(g, cap, variant, monkeypatch, float32=False, **kw):
+def run(g, cap, variant, monkeypatch, float32=False, warm=None, **kw):
     from reveal_graph_embedding_amd import _native
     monkeypatch.setenv("ARCTE_HIP_HOT", str(cap))
+    if warm is None:
+        monkeypatch.delenv("ARCTE_HIP_WARM", raising=False)
+    else:
+        monkeypatch.setenv("ARCTE_HIP_WARM", str(warm))
     w = g["w"]
     rho = g["rho"]
     with _native.Context(w.indptr, w.indices, w.data, g["out_degree"], g["in_degree"], **kw) as ctx:
@@ -43,12 +47,15 @@ def test_every_table_size_matches_the_oracle(name, variant, monkeypatch):
     w = g["w"]
     o_colptr, o_rows, _, o_nop, o_stats = oracle.worker(w, g["out_degree"], g["in_degree"], g["all_seeds"], g["rho"],
                                                         g["epsilon"], want_stats=True, variant=variant)
-    for cap in (0, 4, 32, -1):
-        colptr, rows, nop, stats = run(g, cap, variant, monkeypatch)
-        assert np.array_equal(colptr, o_colptr), "hot cap %d" % cap
-        assert np.array_equal(nop, o_nop), "hot cap %d" % cap
-        assert np.array_equal(sorted_rows(colptr, rows), o_rows), "hot cap %d" % cap
-        assert stats == list(o_stats), "hot cap %d" % cap
+    # (LDS table size, warm-table end rank): off; LDS only; LDS + warm + dense mixed inside one tile; no LDS share but
+    # warm; everything in LDS / warm (the defaults on a graph this small)
+    for cap, warm in ((0, 0), (4, 0), (4, 24), (32, 100), (4, None), (-1, None)):
+        colptr, rows, nop, stats = run(g, cap, variant, monkeypatch, warm=warm)
+        tag = "hot cap %d, warm end %s" % (cap, warm)
+        assert np.array_equal(colptr, o_colptr), tag
+        assert np.array_equal(nop, o_nop), tag
+        assert np.array_equal(sorted_rows(colptr, rows), o_rows), tag
+        assert stats == list(o_stats), tag
 
 
 @pytest.mark.parametrize("shape", [dict(n_slots=4), dict(n_slots=512), dict()])
@@ -69,8 +76,8 @@ def test_launch_shapes(shape, monkeypatch):
 def test_float32_table_is_invisible_too(variant, monkeypatch):
     g = load_golden("rmat2000")
     ref = run(g, 0, variant, monkeypatch, float32=True)
-    for cap in (16, -1):
-        got = run(g, cap, variant, monkeypatch, float32=True)
+    for cap, warm in ((16, 0), (16, 200), (-1, None)):
+        got = run(g, cap, variant, monkeypatch, float32=True, warm=warm)
         assert np.array_equal(got[0], ref[0]) and np.array_equal(got[2], ref[2]) and got[3] == ref[3]
         assert np.array_equal(sorted_rows(got[0], got[1]), sorted_rows(ref[0], ref[1]))
 

@@ -1,7 +1,7 @@
 """Launch-shape sweep of the push kernel on the bench graph: wavefronts per CU x hot-table size x tiles.
 
 usage: python tools/hot_sweep.py NODES EDGES STRIDE CONFIG [CONFIG ...]
-  CONFIG = waves_per_cu:hot_cap:tiles[:waves_per_block[:flags[:lds_reserve_kb]]]   flags: 1 = narrow rows off   hot_cap -1 = whatever fits the LDS
+  CONFIG = waves_per_cu:hot_cap:tiles[:waves_per_block[:flags[:lds_reserve_kb[:warm_end_rank]]]]   flags: 1 = narrow rows off   hot_cap -1 = whatever fits the LDS
            share, 0 = table off
 Every configuration must return the same communities (checked by a hash of the per-seed sorted rows).
 """
@@ -53,6 +53,7 @@ def main():
         wpb = parts[3] if len(parts) > 3 else 1
         os.environ["ARCTE_HIP_LDS_RESERVE_KB"] = str(parts[5]) if len(parts) > 5 else "8"
         os.environ["ARCTE_HIP_NARROW"] = "0" if len(parts) > 4 and parts[4] & 1 else "1"
+        os.environ["ARCTE_HIP_WARM"] = str(parts[6]) if len(parts) > 6 else "32768"
         os.environ["ARCTE_HIP_WAVES_PER_CU"] = str(wpc)
         os.environ["ARCTE_HIP_HOT"] = str(cap)
         os.environ["ARCTE_HIP_TILES"] = str(tiles)
@@ -72,8 +73,8 @@ def main():
         if ref is None:
             ref = h
         byt = 52 * st["edges"] + 36 * st["pushes"] + 4 * st["enqueues"] + 36 * st["support"]
-        print("waves/CU %2d hot_cap %6d tiles %d wpb %d narrow %s | slots %5d push_ms %8.2f seeds/s %8.0f Gedges/s %6.2f alg GB/s %6.0f frac %.3f "
-              "dev GB %5.1f ctx %.1fs K %d occ %d hash %s %s" % (wpc, cap, tiles, wpb, ctx.info()["narrow_rows"], ctx.info()["slots"], best, seeds.size / best * 1e3,
+        print("waves/CU %2d hot_cap %6d tiles %d wpb %d narrow %s warm %s | slots %5d push_ms %8.2f seeds/s %8.0f Gedges/s %6.2f alg GB/s %6.0f frac %.3f "
+              "dev GB %5.1f ctx %.1fs K %d occ %d hash %s %s" % (wpc, cap, tiles, wpb, ctx.info()["narrow_rows"], os.environ["ARCTE_HIP_WARM"], ctx.info()["slots"], best, seeds.size / best * 1e3,
                                                     st["edges"] / best / 1e6, byt / best / 1e6, byt / best / 1e6 / 8000, ctx.info()["device_bytes"] / 1e9,
                                                     tc, ctx.info()["hot_values_per_wave"], ctx.launch_occupancy(), h,
                                                     "OK" if h == ref else "MISMATCH"), flush=True)

@@ -34,14 +34,16 @@ def main():
             rec["edges_per_launch"] = b["config"]["per_seed"]["edges"] * b["config"]["seeds_per_step"]
             rec["algorithmic_bytes"] = b["roofline"]["algorithmic_bytes_per_launch"]
             rec["hot_values_per_wave"] = b["config"]["hot_values_per_wave"]
+            rec["narrow_rows"] = b["config"].get("narrow_rows")
+            rec["warm_end_rank"] = b["config"].get("warm_end_rank")
             rec["slots"] = b["config"]["slots_per_gpu"]
         except Exception as e:
             rec["bench_error"] = str(e)
         rows.append(rec)
     print(json.dumps(rows, indent=1))
     print()
-    print("| arm | kernel | slots | hot values/wave | ms/launch | alg GB/s | frac of 8 TB/s | EA rd req/edge | EA wr req/edge | TCC hit rate | FETCH+WRITE GB | wait share |")
-    print("|---|---|---|---|---|---|---|---|---|---|---|---|")
+    print("| arm | kernel | slots | LDS values/wave | warm end rank | ms/launch | alg GB/s | frac of 8 TB/s | EA rd req/edge | EA wr req/edge | TCC hit rate | FETCH+WRITE GB | wait share |")
+    print("|---|---|---|---|---|---|---|---|---|---|---|---|---|")
     for r in rows:
         e = r.get("edges_per_launch", 0) or 1
         ms = r.get("ms_per_launch", float("nan"))
@@ -50,8 +52,8 @@ def main():
         miss = r.get("TCC_MISS_sum", 0.0)
         traffic = (r.get("FETCH_SIZE", 0.0) + r.get("WRITE_SIZE", 0.0)) * 1024 / 1e9
         wait = r.get("SQ_WAIT_ANY", 0.0) / max(r.get("SQ_WAVE_CYCLES", 1.0), 1.0)
-        print("| %s | %s | %s | %s | %.1f | %.0f | %.3f | %.2f | %.2f | %.3f | %.0f | %.2f |" % (
-            r["arm"], r.get("kernel", "?"), r.get("slots", "?"), r.get("hot_values_per_wave", "?"), ms, alg / ms / 1e6 if ms == ms else 0,
+        print("| %s | %s | %s | %s | %s | %.1f | %.0f | %.3f | %.2f | %.2f | %.3f | %.0f | %.2f |" % (
+            r["arm"], r.get("kernel", "?"), r.get("slots", "?"), r.get("hot_values_per_wave", "?"), r.get("warm_end_rank", "?"), ms, alg / ms / 1e6 if ms == ms else 0,
             alg / ms / 1e6 / 8000 if ms == ms else 0, r.get("TCC_EA0_RDREQ_sum", 0) / e, r.get("TCC_EA0_WRREQ_sum", 0) / e,
             hit / max(hit + miss, 1.0), traffic, wait))
 

@@ -20,7 +20,11 @@ def main():
     out_dir, key = sys.argv[1], sys.argv[2]
     commit = sys.argv[3] if len(sys.argv) > 3 else "uncommitted"
     os.makedirs(out_dir, exist_ok=True)
-    from bench import kernel_source_id
+    # the kernel source the measurement belongs to: what bench.py printed while it ran under the profiler
+    def kernel_source_id():
+        with open(os.path.join(PROF, "trace.json")) as f:
+            line = [l for l in f if l.startswith("{")][-1]
+        return json.loads(line)["config"]["kernel_source_id"]
     stats = glob.glob(os.path.join(PROF, "trace", "**", "*kernel_stats.csv"), recursive=True)
     if stats:
         shutil.copy(stats[0], os.path.join(out_dir, "bench_n1_kernel_stats.csv"))
