@@ -49,7 +49,7 @@ int arcte_hip_device_count(int *count);
  * (eps_randomwalk/transition.py:43-99) and what arcte_worker receives
  * (embedding/arcte/arcte.py:279-286): CSR (indptr[n+1], indices[nnz] ascending inside a
  * row, data[nnz]) of W = D_out^-1 A, weighted out_degree[n], in_degree[n].
- * A slot is the scratch of one wavefront (one seed in flight): n_slots = 0 picks 4 wavefronts per compute unit
+ * A slot is the scratch of one wavefront (one seed in flight): n_slots = 0 picks 6 wavefronts per compute unit
  * (ARCTE_HIP_WAVES_PER_CU overrides), fewer when the dense per-slot state would not fit 3/4 of the free memory;
  * the CU's LDS is divided among its resident wavefronts for the hot table.  queue_capacity = 0 picks
  * min(2^20, max(4096, n/16 rounded up to a power of two)) ring entries (the FIFO of similarity.py:180 is

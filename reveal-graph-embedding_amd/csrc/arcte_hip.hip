@@ -514,7 +514,10 @@ int ctx_finish(arcte_hip_ctx *c, int64_t n_slots, int64_t queue_capacity)
     const int wpb = c->waves_per_block;
     int64_t slots = n_slots;
     if (slots <= 0) {
-        c->waves_per_cu = std::max(1, std::min(env_int("ARCTE_HIP_WAVES_PER_CU", 4), 32));
+        // interleaved A/B on the 1M/50M graph with both tables on (profiles/r02/ab_interleaved_*.txt, ms per 81 434
+        // seeds): 4 per CU 104.8, 5: 95.0, 6: 93.1, 7: 93.2, 8: 92.0, 10: 97.7, 12: 94.9 -- flat from 6 to 8; 6 needs
+        // the least memory of those
+        c->waves_per_cu = std::max(1, std::min(env_int("ARCTE_HIP_WAVES_PER_CU", 6), 32));
         slots = (int64_t)c->waves_per_cu * c->cus;
         // keep the slot scratch within a fixed share of the device
         size_t free_b = 0, total_b = 0;

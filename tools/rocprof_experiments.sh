@@ -22,10 +22,10 @@ arm() {  # name, env assignments...
 }
 arm a_r1_shape_tables_off ARCTE_HIP_HOT=0 ARCTE_HIP_WAVES_PER_CU=8 ARCTE_HIP_NARROW=0
 arm b_lds_table_w8 ARCTE_HIP_WAVES_PER_CU=8 ARCTE_HIP_WARM=0 ARCTE_HIP_NARROW=0
-arm c_lds_table_w4 ARCTE_HIP_WARM=0 ARCTE_HIP_NARROW=0
-arm d_lds_table_w4_narrow_rows ARCTE_HIP_WARM=0
-arm e_default_lds_warm_narrow
-arm f_default_tiles4 ARCTE_HIP_TILES=4
-arm g_default_w8 ARCTE_HIP_WAVES_PER_CU=8
+arm c_lds_table_w4 ARCTE_HIP_WAVES_PER_CU=4 ARCTE_HIP_WARM=0 ARCTE_HIP_NARROW=0
+arm d_lds_table_w4_narrow_rows ARCTE_HIP_WAVES_PER_CU=4 ARCTE_HIP_WARM=0
+arm e_lds_warm_narrow_w4 ARCTE_HIP_WAVES_PER_CU=4
+arm f_default_lds_warm_narrow_w6
+arm g_lds_warm_narrow_w8 ARCTE_HIP_WAVES_PER_CU=8
 python3 $R/tools/summarise_experiments.py $OUT > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt
