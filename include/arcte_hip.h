@@ -63,6 +63,11 @@ int arcte_hip_create(int device, int64_t n, int64_t nnz,
 
 int arcte_hip_destroy(arcte_hip_ctx *ctx);
 
+/* arcte_hip_destroy keeps the context's large slot buffers (tens of GB) in a process-wide cache for the next context
+ * of the same shape on that device: freeing and re-allocating them costs seconds in the runtime.  This returns the
+ * cached memory to the driver. */
+int arcte_hip_trim(void);
+
 /*
  * get_natural_random_walk_matrix (eps_randomwalk/transition.py:43-99) and the seed ordering of arcte()
  * (embedding/arcte/arcte.py:610-617) ON THE DEVICE, followed by arcte_hip_create's slot set-up: the caller hands

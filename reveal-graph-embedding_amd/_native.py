@@ -24,6 +24,7 @@ SIGNATURES = {
     "arcte_hip_create": (C.c_int, [C.c_int, C.c_int64, C.c_int64, _i64p, _i32p, _f64p, _f64p, _f64p,
                                    C.c_int64, C.c_int64, C.POINTER(C.c_void_p)]),
     "arcte_hip_destroy": (C.c_int, [C.c_void_p]),
+    "arcte_hip_trim": (C.c_int, []),
     "arcte_hip_create_from_adjacency": (C.c_int, [C.c_int, C.c_int64, C.c_int64, _i64p, _i32p, _f64p, C.c_int64, C.c_int64,
                                                   C.POINTER(C.c_void_p)]),
     "arcte_hip_create_from_coo": (C.c_int, [C.c_int, C.c_int64, C.c_int64, _i32p, _i32p, _f64p, C.c_int, C.c_int64, C.c_int64,
@@ -112,6 +113,11 @@ def device_count():
     n = C.c_int(0)
     _check(lib().arcte_hip_device_count(C.byref(n)))
     return n.value
+
+
+def trim():
+    """Return the slot buffers that destroyed contexts left in the library's cache to the driver."""
+    _check(lib().arcte_hip_trim())
 
 
 def epsilon_effective_scalar(epsilon, seed_degree, neighbor_degrees, device=0):

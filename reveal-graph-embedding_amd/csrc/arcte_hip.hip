@@ -25,6 +25,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <type_traits>
 #include <vector>
@@ -89,6 +90,56 @@ struct DevBuf {
     }
     size_t bytes() const { return count * sizeof(T); }
 };
+
+// The slot buffers are tens of GB.  hipFree of such a buffer is deferred by the runtime and the NEXT large hipMalloc
+// pays for it -- 1.7 to 6 s per allocation on the MI355X boxes (tools/alloc_time.hip) -- which would dominate a
+// second arcte() call in the same process.  So a context hands its big buffers to a small process-wide cache when it
+// is destroyed and the next context of the same shape takes them back (it clears them anyway);
+// arcte_hip_trim() returns the memory to the driver.
+struct BigCacheEntry { int device; void *p; size_t bytes; };
+std::mutex g_big_mutex;
+std::vector<BigCacheEntry> g_big_cache;
+constexpr size_t BIG_BUFFER = (size_t)256 << 20;
+
+template <typename T>
+hipError_t alloc_cached(DevBuf<T> &b, size_t count, int device)
+{
+    b.release();
+    const size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+    if (bytes >= BIG_BUFFER) {
+        std::lock_guard<std::mutex> lock(g_big_mutex);
+        for (size_t i = 0; i < g_big_cache.size(); i++)
+            if (g_big_cache[i].device == device && g_big_cache[i].bytes == bytes) {
+                b.p = (T *)g_big_cache[i].p;
+                b.count = count;
+                b.capacity = std::max<size_t>(count, 1);
+                g_big_cache.erase(g_big_cache.begin() + (long)i);
+                return hipSuccess;
+            }
+        // nothing of that size: whatever is cached for this device is of a stale shape
+        for (size_t i = 0; i < g_big_cache.size();)
+            if (g_big_cache[i].device == device) { (void)hipFree(g_big_cache[i].p); g_big_cache.erase(g_big_cache.begin() + (long)i); }
+            else i++;
+    }
+    return b.alloc(count);
+}
+
+template <typename T>
+void release_cached(DevBuf<T> &b, int device)
+{
+    const size_t bytes = b.capacity * sizeof(T);
+    if (b.p && bytes >= BIG_BUFFER) {
+        std::lock_guard<std::mutex> lock(g_big_mutex);
+        if (g_big_cache.size() < 8) {
+            g_big_cache.push_back({device, (void *)b.p, bytes});
+            b.p = nullptr;
+            b.count = 0;
+            b.capacity = 0;
+            return;
+        }
+    }
+    b.release();
+}
 
 int32_t max_pushes_limit()
 {
@@ -200,17 +251,17 @@ namespace {
 
 int alloc_slots(arcte_hip_ctx *c, int64_t slots, uint32_t qcap)
 {
-    HIP_TRY(c->state.alloc((size_t)slots * c->n));
+    HIP_TRY(alloc_cached(c->state, (size_t)slots * c->n, c->device));
     HIP_TRY(c->slot_epoch.alloc((size_t)slots));
-    HIP_TRY(c->sup.alloc((size_t)slots * c->n));
-    HIP_TRY(c->queue.alloc((size_t)slots * qcap));
+    HIP_TRY(alloc_cached(c->sup, (size_t)slots * c->n, c->device));
+    HIP_TRY(alloc_cached(c->queue, (size_t)slots * qcap, c->device));
     // warm table: one entry per rank in [0, warm_k2) per slot (the first hotK of them lie unused under the LDS table:
     // the LDS share depends on the arithmetic type, the allocation does not)
-    c->warm.release();
+    release_cached(c->warm, c->device);
     c->warm_n = 0;
     if (c->warm_k2 > 0) {
         c->warm_n = c->warm_k2;
-        HIP_TRY(c->warm.alloc((size_t)slots * c->warm_n * 16));
+        HIP_TRY(alloc_cached(c->warm, (size_t)slots * c->warm_n * 16, c->device));
         HIP_TRY(hipMemsetAsync(c->warm.p, 0, c->warm.bytes(), c->stream));
     }
     HIP_TRY(hipMemsetAsync(c->state.p, 0, c->state.bytes(), c->stream));
@@ -863,6 +914,7 @@ int arcte_hip_destroy(arcte_hip_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     c->indptr.release(); c->indices.release(); c->data.release(); c->out_degree.release(); c->in_degree.release();
+    release_cached(c->state, c->device); release_cached(c->sup, c->device); release_cached(c->queue, c->device); release_cached(c->warm, c->device);
     c->state.release(); c->slot_epoch.release(); c->warm.release(); c->contrib_key.release(); c->contrib_val.release(); c->centrality.release(); c->ranked_ids.release(); c->node_hot.release(); c->edge_hot.release(); c->edge_in_degree.release(); c->data_f.release(); c->in_degree_f.release(); c->edge_in_degree_f.release(); c->queue.release(); c->sup.release();
     c->seeds_d.release(); c->work_pos.release(); c->out_cnt.release(); c->status.release(); c->nop_d.release();
     c->eps_d.release(); c->out_off.release(); c->dst_off.release(); c->counters.release();
@@ -2130,6 +2182,17 @@ int arcte_hip_stream_bandwidth(int device, int64_t bytes, double *read_gbps, dou
     if (e1) (void)hipEventDestroy(e1);
     a.release(); b.release(); sink.release();
     return rc;
+}
+
+int arcte_hip_trim(void)
+{
+    std::lock_guard<std::mutex> lock(g_big_mutex);
+    for (auto &e : g_big_cache) {
+        (void)hipSetDevice(e.device);
+        (void)hipFree(e.p);
+    }
+    g_big_cache.clear();
+    return 0;
 }
 
 int arcte_hip_set_float32(arcte_hip_ctx *c, int enable)
