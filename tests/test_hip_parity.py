@@ -408,3 +408,23 @@ def test_config0_ba20000_rho1e3_matches_reference_hash():
     assert f.nnz == int(z["nnz"])
     assert np.array_equal(np.diff(sparse.csc_matrix(f[:, a.shape[0]:]).indptr), z["local_col_counts"])
     assert np.array_equal(digest, z["sha256"])
+
+
+def test_slot_buffers_are_reused_across_contexts_and_trimmed():
+    """A destroyed context leaves its big slot buffers in the library's cache (freeing and re-allocating tens of GB
+    costs seconds); the next context of the same shape takes them back CLEARED: same results, and trim() empties it."""
+    adjacency = rmat_graph(100000, 2000000, seed=0)
+    results = []
+    for _ in range(2):
+        with _native.Context.from_adjacency(adjacency.indptr, adjacency.indices, adjacency.data) as ctx:
+            seeds = np.sort(ctx.seed_list())[::7]
+            ctx.run_seeds(seeds, 0.1, 1e-5)
+            colptr, rows, nop = ctx.fetch(want_nop=True)
+            results.append((colptr, rows, nop))
+    assert all(np.array_equal(a, b) for a, b in zip(results[0], results[1]))
+    _native.trim()
+    with _native.Context.from_adjacency(adjacency.indptr, adjacency.indices, adjacency.data) as ctx:
+        ctx.run_seeds(seeds, 0.1, 1e-5)
+        colptr, rows, nop = ctx.fetch(want_nop=True)
+    assert all(np.array_equal(a, b) for a, b in zip(results[0], (colptr, rows, nop)))
+    _native.trim()
