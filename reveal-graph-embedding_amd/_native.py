@@ -277,13 +277,18 @@ class Context:
             out.append(nop)
         return tuple(out)
 
+    def result_csr_size(self, with_base_block=False):
+        """Stored entries of the matrix fetch_csr() will return."""
+        nnz = C.c_int64(0)
+        _check(lib().arcte_hip_result_csr_size(self._h, 1 if with_base_block else 0, C.byref(nnz)))
+        return int(nnz.value)
+
     def fetch_csr(self, with_base_block=False):
         """The last run as CSR (indptr int64[n+1], indices int32), assembled on the device.  With the base block
         the columns are those of arcte()'s n x 2n matrix.  Seeds must have been unique."""
-        nnz = C.c_int64(0)
-        _check(lib().arcte_hip_result_csr_size(self._h, 1 if with_base_block else 0, C.byref(nnz)))
+        nnz = self.result_csr_size(with_base_block)
         indptr = np.zeros(self.n + 1, dtype=np.int64)
-        indices = np.zeros(max(nnz.value, 1), dtype=np.int32)
+        indices = np.empty(max(nnz, 1), dtype=np.int32)
         got = C.c_int64(0)
         _check(lib().arcte_hip_fetch_result_csr(self._h, 1 if with_base_block else 0, indptr, indices.ctypes.data,
                                                 C.byref(got)))

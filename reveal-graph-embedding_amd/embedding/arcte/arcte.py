@@ -72,6 +72,25 @@ def _finish_base_values(features, rw_transition):
     return _set_self_loop_values(features, row_of[rw_transition.indices == row_of])
 
 
+class _OnesInBackground:
+    """float64 ones of the given length, written by a few threads (ndarray.fill releases the GIL) while the caller
+    waits for the device."""
+
+    def __init__(self, size, threads=8):
+        self._out = np.empty(size, dtype=np.float64)
+        threads = max(1, min(threads, size >> 22))              # one thread per 32 MB at least
+        step = -(-size // threads) if size else 0
+        self._threads = [threading.Thread(target=self._out[k * step:(k + 1) * step].fill, args=(1.0,))
+                         for k in range(threads)] if size else []
+        for t in self._threads:
+            t.start()
+
+    def result(self):
+        for t in self._threads:
+            t.join()
+        return self._out
+
+
 def _features_of_run(ctx, variant, iterate_nodes, rho, epsilon, with_base_block, pattern):
     """Run `iterate_nodes` on the context and return the reference's matrix: n x n local communities
     (arcte.py:379-388) or, with the base block, arcte()'s n x 2n [I + pattern | local] (arcte.py:676-683).
@@ -84,16 +103,21 @@ def _features_of_run(ctx, variant, iterate_nodes, rho, epsilon, with_base_block,
     ctx.run_seeds(iterate_nodes, rho, epsilon, use_effective_epsilon=True, variant=variant,
                   laziness_factor=laziness_factor)
     if with_base_block or np.unique(iterate_nodes).size == iterate_nodes.size:
-        # the device sorts the (row, seed) pairs into the CSR the reference builds via COO (arcte.py:379-388)
+        # the device sorts the (row, seed) pairs into the CSR the reference builds via COO (arcte.py:379-388); the
+        # host meanwhile writes the matrix's values (all ones, arcte.py:381) -- 7 GB on the 1M-node graph
+        ones = None
         try:
+            ones = _OnesInBackground(ctx.result_csr_size(with_base_block))
             indptr, indices = ctx.fetch_csr(with_base_block)
         except _native.ArcteHipError as e:
+            if ones is not None:
+                ones.result()
             if e.code != -3:                      # ARCTE_HIP_ECAPACITY: too many entries for the device assembly
                 raise
         else:
             width = 2 * number_of_nodes if with_base_block else number_of_nodes
             index_dtype = np.int32 if max(width, indices.size) < 2 ** 31 else np.int64
-            return sparse.csr_matrix((np.ones(indices.size, dtype=np.float64), indices.astype(index_dtype, copy=False),
+            return sparse.csr_matrix((ones.result()[:indices.size], indices.astype(index_dtype, copy=False),
                                       indptr.astype(index_dtype)), shape=(number_of_nodes, width))
     colptr, rows = ctx.fetch()
     local = _seed_matrix(number_of_nodes, iterate_nodes, colptr, rows)

@@ -171,3 +171,50 @@ def test_sharded_arcte_and_centrality_with_hip_compute_and_gloo_transport(tmp_pa
     f = sparse.csr_matrix((z["data"], z["indices"], z["indptr"]), shape=tuple(z["shape"]))
     assert_close_sparse(f, g["features"], 1e-12)
     np.testing.assert_allclose(z["centrality"], g["centrality"], rtol=1e-13, atol=0)
+
+
+def _rccl_single_rank_worker(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["LOCAL_RANK"] = "0"
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    from reveal_graph_embedding_amd.distributed import (arcte_and_centrality_distributed, arcte_distributed,
+                                                        gather_shards)
+    from test_centrality_weighting_cpu import load_centrality
+    # the transport by itself: device tensors in, device tensors out
+    counts = torch.tensor([2, 0, 3], dtype=torch.int64, device=dev)
+    rows = torch.tensor([5, 6, 1, 2, 3], dtype=torch.int32, device=dev)
+    (c0, r0), = gather_shards(counts, rows, dst=0)
+    assert c0.is_cuda and r0.is_cuda and c0.tolist() == [2, 0, 3] and r0.tolist() == [5, 6, 1, 2, 3]
+    g = load_golden("rmat2000")
+    f = arcte_distributed(g["adjacency"], g["rho"], g["epsilon"])
+    f.sort_indices()
+    gc = load_centrality("ba300")
+    fc, c = arcte_and_centrality_distributed(gc["adjacency"], float(gc["rho"]), float(gc["epsilon"]))
+    fc.sort_indices()
+    np.savez(out_path, indptr=f.indptr, indices=f.indices, data=f.data, shape=np.array(f.shape), c_indptr=fc.indptr,
+             c_indices=fc.indices, c_data=fc.data, c_shape=np.array(fc.shape), centrality=c)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_drivers_over_rccl_with_one_rank(tmp_path):
+    """What a one-GPU box can show of the RCCL transport: backend "nccl", world size 1 -- process-group set-up on the
+    device, the all_gather of sizes, the float64 all-reduce and the barrier all run through RCCL on device tensors.
+    (The rank-to-rank sends need a second GPU; their code path runs under gloo in the tests above.)"""
+    import scipy.sparse as sparse
+    from test_centrality_weighting_cpu import assert_close_sparse, load_centrality
+    out = str(tmp_path / "f.npz")
+    mp.spawn(_rccl_single_rank_worker, args=(1, _free_port(), out), nprocs=1, join=True)
+    z = np.load(out)
+    f = sparse.csr_matrix((z["data"], z["indices"], z["indptr"]), shape=tuple(z["shape"]))
+    assert_same_sparse(f, load_golden("rmat2000")["feat1"])
+    g = load_centrality("ba300")
+    fc = sparse.csr_matrix((z["c_data"], z["c_indices"], z["c_indptr"]), shape=tuple(z["c_shape"]))
+    assert_close_sparse(fc, g["features"], 1e-12)
+    np.testing.assert_allclose(z["centrality"], g["centrality"], rtol=1e-13, atol=0)

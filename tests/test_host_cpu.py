@@ -83,3 +83,11 @@ def test_rmat_generator_reproduces_survey_counts():
     assert int((deg > 1).sum()) == 63070
     assert int(deg.max()) == 14891
     assert (a != a.T).nnz == 0
+
+
+def test_background_ones_cover_every_entry():
+    from reveal_graph_embedding_amd.embedding.arcte.arcte import _OnesInBackground
+    for size in (0, 1, 5, (1 << 22) * 3 + 17):
+        out = _OnesInBackground(size, threads=4).result()
+        assert out.dtype == np.float64 and out.shape == (size,)
+        assert np.all(out == 1.0)

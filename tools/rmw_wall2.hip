@@ -1,7 +1,7 @@
 // Microbenchmark, round 2: what bounds random entry updates on MI355X, by entry size, write shape and footprint.
 //
 //   rmw_wall2 ENTRY MODE TABLE_MB WAVES_PER_CU PRIVATE STREAM [ITERS]
-//     ENTRY   32 | 64 | 128      bytes per entry, entries aligned to their size
+//     ENTRY   16 | 32 | 64 | 128 bytes per entry, entries aligned to their size
 //     MODE    0 read the whole entry
 //             1 write the whole entry (no read)
 //             2 read the whole entry, write its first 16 bytes          (the push kernel's per-edge pattern)
@@ -113,7 +113,8 @@ int main(int argc, char **argv)
     float best = 1e30f;
     for (int rep = 0; rep < 3; rep++) {
         hipEventRecord(a);
-        if (entry == 32) launch_m<32>(mode, stream_b, dim3(blocks), tab, epd, priv, st, stream_elems, iters, sink);
+        if (entry == 16) launch_m<16>(mode, stream_b, dim3(blocks), tab, epd, priv, st, stream_elems, iters, sink);
+        else if (entry == 32) launch_m<32>(mode, stream_b, dim3(blocks), tab, epd, priv, st, stream_elems, iters, sink);
         else if (entry == 64) launch_m<64>(mode, stream_b, dim3(blocks), tab, epd, priv, st, stream_elems, iters, sink);
         else launch_m<128>(mode, stream_b, dim3(blocks), tab, epd, priv, st, stream_elems, iters, sink);
         hipEventRecord(b);
