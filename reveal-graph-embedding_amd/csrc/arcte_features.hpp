@@ -45,17 +45,24 @@ __global__ void k_feat_multiply_columns(const int32_t *indices, const double *fa
 }
 
 // common.py:40 / community_weighting.py:118-119: sklearn normalize(norm="l2") -- the squares of a row are summed in
-// storage order (sklearn/utils/sparsefuncs_fast.pyx), zero rows stay.  One thread per row keeps that order.
-__global__ void k_feat_normalize_rows(const int64_t *indptr, int64_t nrows, double *data)
+// storage order (sklearn/utils/sparsefuncs_fast.pyx), zero rows stay.  One wavefront per row: coalesced loads, the
+// sum as the same left fold (ordered_add64).
+__global__ __launch_bounds__(BLOCK) void k_feat_normalize_rows(const int64_t *indptr, int64_t nrows, double *data)
 {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
     if (i >= nrows) return;
     const int64_t b = indptr[i], e = indptr[i + 1];
     double acc = 0.0;
-    for (int64_t k = b; k < e; k++) acc += data[k] * data[k];
+    for (int64_t k0 = b; k0 < e; k0 += WAVE) {
+        const int64_t k = k0 + lane;
+        const double x = k < e ? data[k] : 0.0;
+        const int64_t left = e - k0;
+        acc = left >= WAVE ? ordered_add64(acc, x * x) : ordered_add_n(acc, x * x, (int)left);
+    }
     if (acc == 0.0) return;
     const double norm = sqrt(acc);
-    for (int64_t k = b; k < e; k++) data[k] = data[k] / norm;
+    for (int64_t k = b + lane; k < e; k += WAVE) data[k] = data[k] / norm;
 }
 
 // eliminate_zeros() (community_weighting.py:115-116): keep[k] = data[k] != 0

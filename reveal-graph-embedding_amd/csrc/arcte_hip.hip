@@ -196,6 +196,8 @@ struct arcte_hip_ctx {
     // arcte_and_centrality (arcte.pyx:125-241)
     DevBuf<uint64_t> contrib_key;
     DevBuf<double> contrib_val, centrality;
+    int64_t contrib_seed_base = 0;          // the running batch of arcte_hip_run_centrality: key = node << shift | seed - base
+    int contrib_shift = 32;
     int centrality_run = 0;      // the last run was arcte_hip_run_centrality: columns are numbered by a running counter
     DevBuf<int32_t> ranked_ids;  // every node by descending pattern in-count, ties by node id (stable)
     int64_t nseeds_all = 0;      // arcte.py:617: how many of them have an in-count above 1 = the seed list
@@ -1182,6 +1184,8 @@ static int run_seeds_impl(arcte_hip_ctx *c, const int64_t *seeds, int64_t nseeds
         P.contrib_val = c->contrib_val.p;
         P.contrib_cap = c->contrib_key.count;
         P.contrib_cursor = c->counters.p + 8;
+        P.contrib_seed_base = c->contrib_seed_base;
+        P.contrib_shift = c->contrib_shift;
         HIP_TRY(hipEventRecord(c->ev[2], c->stream));
         r = (mode == 2) ? launch_centrality(c, P, nwork) : launch_seeds<0>(c, P, nwork, variant);
         if (r) return r;
@@ -1333,7 +1337,7 @@ int arcte_hip_run_centrality(arcte_hip_ctx *c, int64_t node_begin, int64_t node_
     const int64_t ns = (int64_t)seeds.size();
     HIP_TRY(c->centrality.alloc(c->n));
     HIP_TRY(hipMemsetAsync(c->centrality.p, 0, c->centrality.bytes(), c->stream));
-    // contribution arena of one batch: (node << 32 | seed, value) pairs, sorted and folded per batch
+    // contribution arena of one batch: (node << shift | seed - first seed of the batch, value) pairs, sorted and folded per batch
     if (!c->contrib_key.p) {
         size_t free_b = 0, total_b = 0;
         HIP_TRY(hipMemGetInfo(&free_b, &total_b));
@@ -1349,20 +1353,27 @@ int arcte_hip_run_centrality(arcte_hip_ctx *c, int64_t node_begin, int64_t node_
     DevBuf<int32_t> all_rows;
     DevBuf<uint64_t> key_sorted;
     DevBuf<double> val_sorted;
+    DevBuf<int64_t> run_first, run_last;
     DevBuf<char> temp;
     std::vector<int64_t> all_colptr((size_t)ns + 1, 0);
     int64_t stats_sum[6] = {0, 0, 0, 0, 0, 0}, cand_sum = 0, rows_used = 0;
     double ms_sum[4] = {0, 0, 0, 0};
     auto t0 = std::chrono::steady_clock::now();
+    auto bits_for = [](uint64_t values) { int b = 1; while (b < 63 && ((uint64_t)1 << b) < values) b++; return b; };
     int rc = [&]() -> int {
-        int key_bits = 33;
-        while (key_bits < 64 && ((uint64_t)1 << (key_bits - 32)) < (uint64_t)c->n) key_bits++;
+        const int node_bits = bits_for((uint64_t)c->n);
+        HIP_TRY(run_first.alloc(c->n));
+        HIP_TRY(run_last.alloc(c->n));
         double per_seed = (double)std::min<int64_t>(c->n, 4096);
         int64_t pos = 0;
         while (pos < ns) {
             int64_t batch = std::max<int64_t>(1, std::min<int64_t>(ns - pos, (int64_t)((double)c->contrib_key.count / per_seed)));
             unsigned long long m = 0;
             for (;;) {
+                // the seeds of a batch are ascending node ids: the sort key carries their offset in the batch's id range,
+                // so the radix sort runs over log2(range) + log2(n) bits instead of 32 + log2(n)
+                c->contrib_seed_base = seeds[(size_t)pos];
+                c->contrib_shift = bits_for((uint64_t)(seeds[(size_t)(pos + batch - 1)] - seeds[(size_t)pos] + 1));
                 HIP_TRY(hipMemsetAsync(c->counters.p + 8, 0, sizeof(unsigned long long), c->stream));
                 int r = run_seeds_impl(c, seeds.data() + pos, batch, rho, epsilon, 0, 0, 0.0, 2);
                 if (r < 0) return r;
@@ -1379,6 +1390,7 @@ int arcte_hip_run_centrality(arcte_hip_ctx *c, int64_t node_begin, int64_t node_
             }
             HIP_TRY(hipMemcpy(&m, c->counters.p + 8, sizeof(m), hipMemcpyDeviceToHost));
             if (m) {
+                const int key_bits = c->contrib_shift + node_bits;
                 HIP_TRY(key_sorted.reserve(m));
                 HIP_TRY(val_sorted.reserve(m));
                 size_t tb = 0;
@@ -1387,8 +1399,12 @@ int arcte_hip_run_centrality(arcte_hip_ctx *c, int64_t node_begin, int64_t node_
                 HIP_TRY(temp.reserve(tb));
                 HIP_TRY(hipcub::DeviceRadixSort::SortPairs(temp.p, tb, c->contrib_key.p, key_sorted.p, c->contrib_val.p, val_sorted.p, (size_t)m, 0,
                                                            key_bits, c->stream));
-                hipLaunchKernelGGL(k_apply_contributions, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream, key_sorted.p, val_sorted.p,
-                                   (int64_t)m, c->centrality.p);
+                HIP_TRY(hipMemsetAsync(run_first.p, 0, run_first.bytes(), c->stream));
+                HIP_TRY(hipMemsetAsync(run_last.p, 0, run_last.bytes(), c->stream));
+                hipLaunchKernelGGL(k_contribution_bounds, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream, key_sorted.p, (int64_t)m,
+                                   c->contrib_shift, run_first.p, run_last.p);
+                hipLaunchKernelGGL(k_apply_contributions, dim3((unsigned)((c->n + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK)), dim3(BLOCK), 0, c->stream,
+                                   val_sorted.p, run_first.p, run_last.p, c->n, c->centrality.p);
                 HIP_TRY(hipGetLastError());
             }
             // this batch's communities behind the earlier ones
@@ -1422,7 +1438,7 @@ int arcte_hip_run_centrality(arcte_hip_ctx *c, int64_t node_begin, int64_t node_
         HIP_TRY(hipStreamSynchronize(c->stream));
         return 0;
     }();
-    key_sorted.release(); val_sorted.release(); temp.release();
+    key_sorted.release(); val_sorted.release(); temp.release(); run_first.release(); run_last.release();
     if (rc) { all_rows.release(); c->run_nseeds = -1; return rc; }
     c->rows_final.release();
     c->rows_final = all_rows;
@@ -1803,14 +1819,19 @@ struct arcte_hip_features {
     DevBuf<int64_t> indptr;
     DevBuf<int32_t> indices;
     DevBuf<double> data;
+    DevBuf<uint32_t> col_count;             // stored entries per column of the CURRENT pattern (valid while col_count_valid)
+    bool col_count_valid = false;
 };
 
-static int column_counts(arcte_hip_features *f, DevBuf<uint32_t> &count)
+// Stored entries per column; kept with the matrix until its pattern changes (every weighting step asks for them)
+static int column_counts(arcte_hip_features *f)
 {
-    HIP_TRY(count.alloc(f->n_cols));
-    HIP_TRY(hipMemset(count.p, 0, count.bytes()));
-    if (f->nnz) hipLaunchKernelGGL(k_feat_column_counts, dim3((unsigned)((f->nnz + 255) / 256)), dim3(256), 0, 0, f->indices.p, f->nnz, count.p);
+    if (f->col_count_valid) return 0;
+    HIP_TRY(f->col_count.alloc(f->n_cols));
+    HIP_TRY(hipMemset(f->col_count.p, 0, f->col_count.bytes()));
+    if (f->nnz) hipLaunchKernelGGL(k_feat_column_counts, dim3((unsigned)((f->nnz + 255) / 256)), dim3(256), 0, 0, f->indices.p, f->nnz, f->col_count.p);
     HIP_TRY(hipGetLastError());
+    f->col_count_valid = true;
     return 0;
 }
 
@@ -1818,7 +1839,7 @@ int arcte_hip_features_destroy(arcte_hip_features *f)
 {
     if (!f) return 0;
     (void)hipSetDevice(f->device);
-    f->indptr.release(); f->indices.release(); f->data.release();
+    f->indptr.release(); f->indices.release(); f->data.release(); f->col_count.release();
     delete f;
     return 0;
 }
@@ -1951,19 +1972,18 @@ int arcte_hip_features_normalize_columns(arcte_hip_features *f)
 {
     if (!f) return fail(ARCTE_HIP_EINVAL, "features is NULL");
     HIP_TRY(hipSetDevice(f->device));
-    DevBuf<uint32_t> count;
     DevBuf<double> divisor;
     int rc = [&]() -> int {
-        int r = column_counts(f, count);
+        int r = column_counts(f);
         if (r) return r;
         HIP_TRY(divisor.alloc(f->n_cols));
-        hipLaunchKernelGGL(k_feat_idf, dim3((unsigned)((f->n_cols + 255) / 256)), dim3(256), 0, 0, count.p, f->n_cols, divisor.p);
+        hipLaunchKernelGGL(k_feat_idf, dim3((unsigned)((f->n_cols + 255) / 256)), dim3(256), 0, 0, f->col_count.p, f->n_cols, divisor.p);
         if (f->nnz) hipLaunchKernelGGL(k_feat_divide_columns, dim3((unsigned)((f->nnz + 255) / 256)), dim3(256), 0, 0, f->indices.p, divisor.p, f->nnz, f->data.p);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipDeviceSynchronize());
         return 0;
     }();
-    count.release(); divisor.release();
+    divisor.release();
     return rc;
 }
 
@@ -1971,7 +1991,9 @@ int arcte_hip_features_normalize_rows(arcte_hip_features *f)
 {
     if (!f) return fail(ARCTE_HIP_EINVAL, "features is NULL");
     HIP_TRY(hipSetDevice(f->device));
-    if (f->n_rows) hipLaunchKernelGGL(k_feat_normalize_rows, dim3((unsigned)((f->n_rows + 255) / 256)), dim3(256), 0, 0, f->indptr.p, f->n_rows, f->data.p);
+    if (f->n_rows)
+        hipLaunchKernelGGL(k_feat_normalize_rows, dim3((unsigned)((f->n_rows + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK)), dim3(BLOCK), 0, 0, f->indptr.p,
+                           f->n_rows, f->data.p);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
     return 0;
@@ -1981,27 +2003,26 @@ int arcte_hip_features_community_weighting(arcte_hip_features *f, const double *
 {
     if (!f || !community_weights) return fail(ARCTE_HIP_EINVAL, "bad argument");
     HIP_TRY(hipSetDevice(f->device));
-    DevBuf<uint32_t> count;
     DevBuf<double> w_d, factor, data_out;
     DevBuf<int64_t> pos, indptr_out;
     DevBuf<int32_t> indices_out;
     DevBuf<char> temp;
     int rc = [&]() -> int {
-        int r = column_counts(f, count);
+        int r = column_counts(f);
         if (r) return r;
         HIP_TRY(w_d.alloc(f->n_cols));
         HIP_TRY(factor.alloc(f->n_cols));
         HIP_TRY(hipMemcpy(w_d.p, community_weights, f->n_cols * sizeof(double), hipMemcpyHostToDevice));
-        hipLaunchKernelGGL(k_feat_reinforcement, dim3((unsigned)((f->n_cols + 255) / 256)), dim3(256), 0, 0, count.p, w_d.p, f->n_cols, factor.p);
+        hipLaunchKernelGGL(k_feat_reinforcement, dim3((unsigned)((f->n_cols + 255) / 256)), dim3(256), 0, 0, f->col_count.p, w_d.p, f->n_cols, factor.p);
         if (f->nnz) {
             hipLaunchKernelGGL(k_feat_multiply_columns, dim3((unsigned)((f->nnz + 255) / 256)), dim3(256), 0, 0, f->indices.p, factor.p, f->nnz, f->data.p);
             // eliminate_zeros() (:115-116)
             HIP_TRY(pos.alloc(f->nnz));
             hipLaunchKernelGGL(k_feat_nonzero_flags, dim3((unsigned)((f->nnz + 255) / 256)), dim3(256), 0, 0, f->data.p, f->nnz, pos.p);
             size_t tb = 0;
-            HIP_TRY(hipcub::DeviceScan::InclusiveSum(nullptr, tb, pos.p, pos.p, (int)f->nnz, 0));
+            HIP_TRY(hipcub::DeviceScan::InclusiveSum(nullptr, tb, pos.p, pos.p, (size_t)f->nnz, 0));
             HIP_TRY(temp.alloc(tb));
-            HIP_TRY(hipcub::DeviceScan::InclusiveSum(temp.p, tb, pos.p, pos.p, (int)f->nnz, 0));
+            HIP_TRY(hipcub::DeviceScan::InclusiveSum(temp.p, tb, pos.p, pos.p, (size_t)f->nnz, 0));
             int64_t kept = 0;
             HIP_TRY(hipMemcpy(&kept, pos.p + (f->nnz - 1), sizeof(int64_t), hipMemcpyDeviceToHost));
             if (kept != f->nnz) {
@@ -2019,12 +2040,13 @@ int arcte_hip_features_community_weighting(arcte_hip_features *f, const double *
                 f->data = data_out; data_out.p = nullptr;
                 f->indptr = indptr_out; indptr_out.p = nullptr;
                 f->nnz = kept;
+                f->col_count_valid = false;          // the pattern changed
             }
         }
         HIP_TRY(hipGetLastError());
         return 0;
     }();
-    count.release(); w_d.release(); factor.release(); data_out.release(); pos.release(); indptr_out.release(); indices_out.release(); temp.release();
+    w_d.release(); factor.release(); data_out.release(); pos.release(); indptr_out.release(); indices_out.release(); temp.release();
     if (rc) return rc;
     return arcte_hip_features_normalize_rows(f);        // :118-119
 }
@@ -2084,7 +2106,6 @@ int arcte_hip_features_chi2_psnr_weights(arcte_hip_features *f, const int64_t *y
     DevBuf<int64_t> yp;
     DevBuf<int32_t> yi;
     DevBuf<double> m, class_count, variance, weights;
-    DevBuf<uint32_t> count;
     int rc = [&]() -> int {
         HIP_TRY(yp.alloc(f->n_rows + 1));
         HIP_TRY(yi.alloc(ny));
@@ -2096,7 +2117,7 @@ int arcte_hip_features_chi2_psnr_weights(arcte_hip_features *f, const int64_t *y
         if (ny) HIP_TRY(hipMemcpy(yi.p, y_indices, ny * sizeof(int32_t), hipMemcpyHostToDevice));
         HIP_TRY(hipMemset(m.p, 0, m.bytes()));
         HIP_TRY(hipMemset(class_count.p, 0, class_count.bytes()));
-        int r = column_counts(f, count);        // feature_count = X.sum(axis=0) of the ones pattern (:29)
+        int r = column_counts(f);               // feature_count = X.sum(axis=0) of the ones pattern (:29)
         if (r) return r;
         if (f->n_rows) {
             int blocks = (int)((f->n_rows + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
@@ -2104,7 +2125,7 @@ int arcte_hip_features_chi2_psnr_weights(arcte_hip_features *f, const int64_t *y
                                class_count.p);
         }
         const int64_t cells = n_classes * f->n_cols;
-        hipLaunchKernelGGL(k_chi2_statistic, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, 0, class_count.p, count.p, f->n_rows, n_classes,
+        hipLaunchKernelGGL(k_chi2_statistic, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, 0, class_count.p, f->col_count.p, f->n_rows, n_classes,
                            f->n_cols, m.p);
         hipLaunchKernelGGL(k_psnr_row_variance, dim3((unsigned)n_classes), dim3(256), 0, 0, m.p, f->n_cols, variance.p);
         hipLaunchKernelGGL(k_psnr_weights, dim3((unsigned)((f->n_cols + 255) / 256)), dim3(256), 0, 0, m.p, n_classes, f->n_cols, variance.p, weights.p);
@@ -2114,7 +2135,7 @@ int arcte_hip_features_chi2_psnr_weights(arcte_hip_features *f, const int64_t *y
         HIP_TRY(hipMemcpy(weights_out, weights.p, f->n_cols * sizeof(double), hipMemcpyDeviceToHost));
         return 0;
     }();
-    yp.release(); yi.release(); m.release(); class_count.release(); variance.release(); weights.release(); count.release();
+    yp.release(); yi.release(); m.release(); class_count.release(); variance.release(); weights.release();
     return rc;
 }
 

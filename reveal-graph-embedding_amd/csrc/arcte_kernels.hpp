@@ -386,25 +386,69 @@ struct PushParams {
     int32_t *status;
     int32_t *nop;
     unsigned long long *stats;   // [0] pushes [1] edges [2] enqueues [3] support [4] failed seeds [5] candidates
-    // MODE 2: (node << 32 | seed, s/in_degree) of every support node of every seed, for the centrality accumulation
+    // MODE 2: (node << contrib_shift | seed - contrib_seed_base, s/in_degree) of every support node of every seed of
+    // the batch, for the centrality accumulation (the seeds of a batch are a block of ascending node ids)
     uint64_t *contrib_key;
     double *contrib_val;
     unsigned long long contrib_cap;
     unsigned long long *contrib_cursor;
+    int64_t contrib_seed_base;
+    int contrib_shift;
 };
 
-// arcte.pyx:190-191: centrality += s_norm, seed after seed.  The contributions of a batch of seeds, sorted by
-// (node, seed): one thread per node folds its run into centrality[node] in ascending seed order -- per node exactly
-// the reference's sequence of additions.
-__global__ void k_apply_contributions(const uint64_t *keys, const double *vals, int64_t m, double *centrality)
+// Lane j's double as a wavefront-uniform value (j uniform)
+__device__ __forceinline__ double lane_value(double x, int j)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), j);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(x), j);
+    return __hiloint2double(hi, lo);
+}
+
+// acc + x[lane 0] + x[lane 1] + ... in exactly that order: the left fold a sequential CPU loop performs, fed by
+// coalesced 64-value loads.  The chain is one dependent add per value whichever way it is laid out; this way the
+// memory side streams.
+__device__ __forceinline__ double ordered_add64(double acc, double x)
+{
+#pragma unroll
+    for (int j = 0; j < WAVE; j++) acc += lane_value(x, j);
+    return acc;
+}
+
+__device__ __forceinline__ double ordered_add_n(double acc, double x, int count)       // count uniform, < 64
+{
+    for (int j = 0; j < count; j++) acc += lane_value(x, j);
+    return acc;
+}
+
+// The contributions of a batch, sorted by (node, seed): where each node's run begins and ends (both 0 = no run;
+// the caller zeroes the arrays)
+__global__ void k_contribution_bounds(const uint64_t *keys, int64_t m, int shift, int64_t *first, int64_t *last)
 {
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= m) return;
-    const uint32_t v = (uint32_t)(keys[k] >> 32);
-    if (k != 0 && (uint32_t)(keys[k - 1] >> 32) == v) return;
+    const uint64_t v = keys[k] >> shift;
+    if (k == 0 || (keys[k - 1] >> shift) != v) first[v] = k;
+    if (k == m - 1 || (keys[k + 1] >> shift) != v) last[v] = k + 1;
+}
+
+// arcte.pyx:190-191: centrality += s_norm, seed after seed.  One wavefront per node folds the node's run into
+// centrality[node] in ascending seed order -- per node exactly the reference's sequence of additions.
+__global__ __launch_bounds__(BLOCK) void k_apply_contributions(const double *vals, const int64_t *first, const int64_t *last, int64_t n,
+                                                               double *centrality)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t v = (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (v >= n) return;
+    const int64_t b = first[v], e = last[v];
+    if (b == e) return;
     double acc = centrality[v];
-    for (int64_t j = k; j < m && (uint32_t)(keys[j] >> 32) == v; j++) acc += vals[j];
-    centrality[v] = acc;
+    for (int64_t k0 = b; k0 < e; k0 += WAVE) {
+        const int64_t k = k0 + lane;
+        const double x = k < e ? vals[k] : 0.0;
+        const int64_t left = e - k0;
+        acc = left >= WAVE ? ordered_add64(acc, x) : ordered_add_n(acc, x, (int)left);
+    }
+    if (lane == 0) centrality[v] = acc;
 }
 
 // arcte.pyx:210: nodes that were no seeds (no out-edges) get centrality 1
@@ -905,7 +949,7 @@ __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
                         if (MODE == 2) {
                             sel = sel && !missing;
                             if (contribute) {
-                                P.contrib_key[coff + i] = ((uint64_t)(uint32_t)v << 32) | (uint32_t)seed;
+                                P.contrib_key[coff + i] = ((uint64_t)(uint32_t)v << P.contrib_shift) | (uint64_t)(seed - P.contrib_seed_base);
                                 P.contrib_val[coff + i] = (double)xn;
                             }
                         }

@@ -8,8 +8,10 @@ OUT=$R/gpurun_out/rmw_wall3.txt
 : > $OUT
 for wpc in 6 8; do
   for tab in 32768 2048; do
-    for em in "32 0" "32 1" "32 2" "32 3" "16 0" "16 1" "16 3" "64 0" "64 1"; do
-      timeout -k 5 60 $B $em $tab $wpc 1 16 >> $OUT || exit 1
+    for st in 16 0; do
+      for em in "32 0" "32 1" "32 2" "32 3" "16 0" "16 1" "16 3" "64 0" "64 1" "64 2" "64 3"; do
+        timeout -k 5 60 $B $em $tab $wpc 1 $st >> $OUT || exit 1
+      done
     done
   done
 done
