@@ -130,7 +130,7 @@ void release_cached(DevBuf<T> &b, int device)
     const size_t bytes = b.capacity * sizeof(T);
     if (b.p && bytes >= BIG_BUFFER) {
         std::lock_guard<std::mutex> lock(g_big_mutex);
-        if (g_big_cache.size() < 8) {
+        if (g_big_cache.size() < 16) {
             g_big_cache.push_back({device, (void *)b.p, bytes});
             b.p = nullptr;
             b.count = 0;
@@ -198,6 +198,10 @@ struct arcte_hip_ctx {
     DevBuf<double> contrib_val, centrality;
     int64_t contrib_seed_base = 0;          // the running batch of arcte_hip_run_centrality: key = node << shift | seed - base
     int contrib_shift = 32;
+    DevBuf<uint64_t> contrib_key_sorted;    // sort output of one batch; kept with the context like the arena itself
+    DevBuf<double> contrib_val_sorted;
+    DevBuf<char> contrib_temp;
+    DevBuf<int64_t> run_first, run_last;    // per node: its run in the sorted batch
     int centrality_run = 0;      // the last run was arcte_hip_run_centrality: columns are numbered by a running counter
     DevBuf<int32_t> ranked_ids;  // every node by descending pattern in-count, ties by node id (stable)
     int64_t nseeds_all = 0;      // arcte.py:617: how many of them have an in-count above 1 = the seed list
@@ -917,6 +921,9 @@ int arcte_hip_destroy(arcte_hip_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     c->indptr.release(); c->indices.release(); c->data.release(); c->out_degree.release(); c->in_degree.release();
     release_cached(c->state, c->device); release_cached(c->sup, c->device); release_cached(c->queue, c->device); release_cached(c->warm, c->device);
+    release_cached(c->contrib_key, c->device); release_cached(c->contrib_val, c->device);
+    release_cached(c->contrib_key_sorted, c->device); release_cached(c->contrib_val_sorted, c->device);
+    c->contrib_temp.release(); c->run_first.release(); c->run_last.release();
     c->state.release(); c->slot_epoch.release(); c->warm.release(); c->contrib_key.release(); c->contrib_val.release(); c->centrality.release(); c->ranked_ids.release(); c->node_hot.release(); c->edge_hot.release(); c->edge_in_degree.release(); c->data_f.release(); c->in_degree_f.release(); c->edge_in_degree_f.release(); c->queue.release(); c->sup.release();
     c->seeds_d.release(); c->work_pos.release(); c->out_cnt.release(); c->status.release(); c->nop_d.release();
     c->eps_d.release(); c->out_off.release(); c->dst_off.release(); c->counters.release();
@@ -1341,20 +1348,20 @@ int arcte_hip_run_centrality(arcte_hip_ctx *c, int64_t node_begin, int64_t node_
     if (!c->contrib_key.p) {
         size_t free_b = 0, total_b = 0;
         HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-        size_t cap = std::min<size_t>((size_t)1 << 29, free_b / 8 / 16);
+        size_t cap = std::min<size_t>((size_t)1 << 29, free_b / 8 / 16);       // larger batches sort slower (measured: 2^29 1.36 s, 2^30 1.53 s, 2^31 1.88 s)
         if (const char *env = getenv("ARCTE_HIP_CONTRIB_ENTRIES")) {   // test hook: force small batches
             long long v = atoll(env);
             if (v > 0) cap = (size_t)v;
         }
         cap = std::max<size_t>(cap, (size_t)c->n);
-        HIP_TRY(c->contrib_key.alloc(cap));
-        HIP_TRY(c->contrib_val.alloc(cap));
+        HIP_TRY(alloc_cached(c->contrib_key, cap, c->device));
+        HIP_TRY(alloc_cached(c->contrib_val, cap, c->device));
     }
     DevBuf<int32_t> all_rows;
-    DevBuf<uint64_t> key_sorted;
-    DevBuf<double> val_sorted;
-    DevBuf<int64_t> run_first, run_last;
-    DevBuf<char> temp;
+    DevBuf<uint64_t> &key_sorted = c->contrib_key_sorted;
+    DevBuf<double> &val_sorted = c->contrib_val_sorted;
+    DevBuf<int64_t> &run_first = c->run_first, &run_last = c->run_last;
+    DevBuf<char> &temp = c->contrib_temp;
     std::vector<int64_t> all_colptr((size_t)ns + 1, 0);
     int64_t stats_sum[6] = {0, 0, 0, 0, 0, 0}, cand_sum = 0, rows_used = 0;
     double ms_sum[4] = {0, 0, 0, 0};
@@ -1362,8 +1369,10 @@ int arcte_hip_run_centrality(arcte_hip_ctx *c, int64_t node_begin, int64_t node_
     auto bits_for = [](uint64_t values) { int b = 1; while (b < 63 && ((uint64_t)1 << b) < values) b++; return b; };
     int rc = [&]() -> int {
         const int node_bits = bits_for((uint64_t)c->n);
-        HIP_TRY(run_first.alloc(c->n));
-        HIP_TRY(run_last.alloc(c->n));
+        if (!run_first.p) {
+            HIP_TRY(run_first.alloc(c->n));
+            HIP_TRY(run_last.alloc(c->n));
+        }
         double per_seed = (double)std::min<int64_t>(c->n, 4096);
         int64_t pos = 0;
         while (pos < ns) {
@@ -1380,8 +1389,8 @@ int arcte_hip_run_centrality(arcte_hip_ctx *c, int64_t node_begin, int64_t node_
                 if (r == RC_CONTRIB_FULL) {
                     if (batch == 1) {
                         size_t want = c->contrib_key.count * 2;
-                        HIP_TRY(c->contrib_key.alloc(want));
-                        HIP_TRY(c->contrib_val.alloc(want));
+                        HIP_TRY(alloc_cached(c->contrib_key, want, c->device));
+                        HIP_TRY(alloc_cached(c->contrib_val, want, c->device));
                     } else batch = std::max<int64_t>(1, batch / 2);
                     continue;
                 }
@@ -1391,8 +1400,10 @@ int arcte_hip_run_centrality(arcte_hip_ctx *c, int64_t node_begin, int64_t node_
             HIP_TRY(hipMemcpy(&m, c->counters.p + 8, sizeof(m), hipMemcpyDeviceToHost));
             if (m) {
                 const int key_bits = c->contrib_shift + node_bits;
-                HIP_TRY(key_sorted.reserve(m));
-                HIP_TRY(val_sorted.reserve(m));
+                if (key_sorted.count < c->contrib_key.count) {         // one allocation of the arena's size, not one per batch
+                    HIP_TRY(alloc_cached(key_sorted, c->contrib_key.count, c->device));
+                    HIP_TRY(alloc_cached(val_sorted, c->contrib_key.count, c->device));
+                }
                 size_t tb = 0;
                 HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, c->contrib_key.p, key_sorted.p, c->contrib_val.p, val_sorted.p, (size_t)m, 0,
                                                            key_bits, c->stream));
@@ -1438,7 +1449,6 @@ int arcte_hip_run_centrality(arcte_hip_ctx *c, int64_t node_begin, int64_t node_
         HIP_TRY(hipStreamSynchronize(c->stream));
         return 0;
     }();
-    key_sorted.release(); val_sorted.release(); temp.release(); run_first.release(); run_last.release();
     if (rc) { all_rows.release(); c->run_nseeds = -1; return rc; }
     c->rows_final.release();
     c->rows_final = all_rows;
