@@ -149,8 +149,8 @@ int arcte_hip_run_seeds_variant(arcte_hip_ctx *ctx, const int64_t *seeds, int64_
  * single-process driver, for the nodes in [node_begin, node_end): every node WITH out-edges is a seed, in index order;
  * the propagation runs with the RAW epsilon; s/in_degree of every support node is added to a centrality vector in
  * seed order (per node a left fold, exactly the reference's sequence of additions: the contributions of a batch of
- * seeds are sorted by (node, seed) on the device and folded by one thread per node); the community is everything at
- * or above the smallest value inside the closed neighbourhood, emitted iff it has more members than that
+ * seeds are sorted by (node, seed) on the device and folded in that order by one wavefront per node); the community is
+ * everything at or above the smallest value inside the closed neighbourhood, emitted iff it has more members than that
  * neighbourhood (a set: a self-loop does not count twice).  Where a node outside the neighbourhood TIES with that
  * smallest value the reference's own answer depends on numpy's unstable argsort (arcte.pyx:194-208); this takes it.
  * Nodes of the range without out-edges get centrality 1.0 (arcte.pyx:210).  Results: arcte_hip_fetch_result (one
