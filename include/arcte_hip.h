@@ -206,8 +206,8 @@ int arcte_hip_copy_result_rows_to_device(arcte_hip_ctx *ctx, void *dst_dev, int6
 int arcte_hip_run_stats(arcte_hip_ctx *ctx, int64_t stats[6]);
 
 /* Extensible form of the above: out[0..n) = pushes, edges, enqueues, support, re-runs, launches, candidates
- * (nodes the extraction had to examine: those whose s/in_degree reached the lower bound of the threshold);
- * entries past the known counters are zero. */
+ * (nodes the extraction had to examine: those whose s/in_degree reached the lower bound of the threshold), rows that
+ * a helper wavefront took half of (launch shape ARCTE_HIP_COOP=1, else 0); entries past the known counters are zero. */
 int arcte_hip_run_counters(arcte_hip_ctx *ctx, int64_t *out, int n);
 
 /*

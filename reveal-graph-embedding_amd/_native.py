@@ -310,10 +310,10 @@ class Context:
         return colptr
 
     def stats(self):
-        s = np.zeros(7, dtype=np.int64)
+        s = np.zeros(8, dtype=np.int64)
         _check(lib().arcte_hip_run_counters(self._h, s, s.size))
         return dict(pushes=int(s[0]), edges=int(s[1]), enqueues=int(s[2]), support=int(s[3]),
-                    reruns=int(s[4]), launches=int(s[5]), candidates=int(s[6]))
+                    reruns=int(s[4]), launches=int(s[5]), candidates=int(s[6]), split_rows=int(s[7]))
 
     def timing(self):
         t = np.zeros(4, dtype=np.float64)

@@ -206,6 +206,9 @@ struct arcte_hip_ctx {
     DevBuf<int32_t> ranked_ids;  // every node by descending pattern in-count, ties by node id (stable)
     int64_t nseeds_all = 0;      // arcte.py:617: how many of them have an in-count above 1 = the seed list
     int waves_per_block = 1;     // wavefronts per workgroup of k_arcte_seeds
+    int coop = 0;                // a helper wavefront per seed walks the second half of long rows (CoopShared)
+    int64_t coop_min = 512;      // rows of at least this many edges are split
+    DevBuf<QEntry> hqueue;       // [slots][qcap] the helpers' staging rings
     int waves_per_cu = 0;        // resident wavefronts per CU the slot count was sized for
     int tiles = 2;               // 64-edge tiles per push iteration
     int narrow = 0;              // uniform row weights + float32-exact in_degrees: the push streams 10 bytes per edge
@@ -227,6 +230,7 @@ struct arcte_hip_ctx {
     std::vector<int64_t> colptr;
     int64_t stats[6] = {0, 0, 0, 0, 0, 0};
     int64_t candidates = 0;
+    int64_t split_rows = 0;      // rows a helper wavefront took half of (ARCTE_HIP_COOP)
     double ms[4] = {0, 0, 0, 0};
 
     GraphDev graph() const
@@ -261,6 +265,8 @@ int alloc_slots(arcte_hip_ctx *c, int64_t slots, uint32_t qcap)
     HIP_TRY(c->slot_epoch.alloc((size_t)slots));
     HIP_TRY(alloc_cached(c->sup, (size_t)slots * c->n, c->device));
     HIP_TRY(alloc_cached(c->queue, (size_t)slots * qcap, c->device));
+    c->hqueue.release();
+    if (c->coop) HIP_TRY(c->hqueue.alloc((size_t)slots * qcap));
     // warm table: one entry per rank in [0, warm_k2) per slot (the first hotK of them lie unused under the LDS table:
     // the LDS share depends on the arithmetic type, the allocation does not)
     release_cached(c->warm, c->device);
@@ -296,6 +302,7 @@ int grow_queue(arcte_hip_ctx *c)
         return alloc_slots(c, slots, nq);
     }
     HIP_TRY(c->queue.alloc((size_t)slots * nq));
+    if (c->coop) HIP_TRY(c->hqueue.alloc((size_t)slots * nq));
     c->qcap = nq;
     return 0;
 }
@@ -323,8 +330,11 @@ uint32_t hot_values_per_wave(const arcte_hip_ctx *c, size_t value_bytes)
     // workgroups per CU (launch-shape sweeps: 3 x 52 KiB, 5 x 32 KiB, 6 x 26 KiB and, on some boxes, 4 x 40 KiB ran
     // like one workgroup fewer); 8 KiB are left unclaimed.
     const size_t reserve = (size_t)std::max(0, env_int("ARCTE_HIP_LDS_RESERVE_KB", 8)) * 1024;
-    size_t per_wave = (LDS_PER_CU - std::min(reserve, LDS_PER_CU / 2)) / (size_t)c->waves_per_cu;
+    // (with helpers a seed has two wavefronts: half as many tables per CU, and CoopShared behind each)
+    const size_t shares = (size_t)std::max(1, c->coop ? c->waves_per_cu / 2 : c->waves_per_cu);
+    size_t per_wave = (LDS_PER_CU - std::min(reserve, LDS_PER_CU / 2)) / shares;
     per_wave = per_wave / 1024 * 1024;
+    if (c->coop) per_wave -= 256;
     uint64_t k = per_wave / value_bytes;
     k = std::min<uint64_t>(k, (uint64_t)c->hot_ranked);
     if (cap > 0) k = std::min<uint64_t>(k, (uint64_t)cap);
@@ -359,6 +369,15 @@ int launch_seeds_v(arcte_hip_ctx *c, PushParams P, int64_t nwork)
     P.hotK = hot_values_per_wave(c, sizeof(T));
     const size_t lds = (size_t)wpb * P.hotK * sizeof(T);
     if (P.hotK == 0) return launch_with_lds(k_arcte_seeds<MODE, VAR, T, 2, false>, blocks, wpb * WAVE, lds, c->stream, P);
+    if constexpr (std::is_same<T, double>::value && MODE == 0 && VAR == 0) {
+        if (c->coop) {
+            // one workgroup of two wavefronts per seed: leader + helper
+            const int seeds_in_flight = (int)std::min<int64_t>(c->slots, std::max<int64_t>(nwork, 1));
+            const size_t lds2 = (size_t)P.hotK * sizeof(T) + sizeof(CoopShared);
+            if (c->narrow) return launch_with_lds(k_arcte_seeds<0, 0, double, 2, true, true, true>, seeds_in_flight, 2 * WAVE, lds2, c->stream, P);
+            return launch_with_lds(k_arcte_seeds<0, 0, double, 2, true, false, true>, seeds_in_flight, 2 * WAVE, lds2, c->stream, P);
+        }
+    }
     if constexpr (std::is_same<T, double>::value) {
         if (c->narrow && c->tiles == 4) return launch_with_lds(k_arcte_seeds<MODE, VAR, T, 4, true, true>, blocks, wpb * WAVE, lds, c->stream, P);
         if (c->narrow) return launch_with_lds(k_arcte_seeds<MODE, VAR, T, 2, true, true>, blocks, wpb * WAVE, lds, c->stream, P);
@@ -567,6 +586,9 @@ int ctx_finish(arcte_hip_ctx *c, int64_t n_slots, int64_t queue_capacity)
     c->warm_k2 = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(env_int("ARCTE_HIP_WARM", 32768), c->hot_ranked));
     if (env_int("ARCTE_HIP_HOT", -1) == 0) c->warm_k2 = 0;
     c->waves_per_block = std::max(1, std::min(env_int("ARCTE_HIP_WAVES_PER_BLOCK", 1), WAVES_PER_BLOCK));
+    c->coop = env_int("ARCTE_HIP_COOP", 0) != 0 && env_int("ARCTE_HIP_HOT", -1) != 0;
+    c->coop_min = std::max(2 * 128, env_int("ARCTE_HIP_COOP_MIN", 512));
+    if (c->coop) c->waves_per_block = 1;
     c->tiles = env_int("ARCTE_HIP_TILES", 2) == 4 ? 4 : 2;
     const int wpb = c->waves_per_block;
     int64_t slots = n_slots;
@@ -574,16 +596,17 @@ int ctx_finish(arcte_hip_ctx *c, int64_t n_slots, int64_t queue_capacity)
         // interleaved A/B on the 1M/50M graph with both tables on (profiles/r02/ab_interleaved_*.txt, ms per 81 434
         // seeds): 4 per CU 104.8, 5: 95.0, 6: 93.1, 7: 93.2, 8: 92.0, 10: 97.7, 12: 94.9 -- flat from 6 to 8; 6 needs
         // the least memory of those
-        c->waves_per_cu = std::max(1, std::min(env_int("ARCTE_HIP_WAVES_PER_CU", 6), 32));
+        c->waves_per_cu = std::max(1, std::min(env_int("ARCTE_HIP_WAVES_PER_CU", c->coop ? 8 : 6), 32));
         slots = (int64_t)c->waves_per_cu * c->cus;
+        if (c->coop) slots = (int64_t)std::max(1, c->waves_per_cu / 2) * c->cus;       // a slot = a seed = two wavefronts
         // keep the slot scratch within a fixed share of the device
         size_t free_b = 0, total_b = 0;
         HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-        size_t per_slot = (size_t)n * (sizeof(Entry) + sizeof(int32_t)) + (size_t)default_queue_capacity(n) * sizeof(QEntry) + (size_t)c->warm_k2 * 16;
+        size_t per_slot = (size_t)n * (sizeof(Entry) + sizeof(int32_t)) + (size_t)default_queue_capacity(n) * sizeof(QEntry) * (c->coop ? 2 : 1) + (size_t)c->warm_k2 * 16;
         while (slots > c->cus && (size_t)slots * per_slot > free_b / 4 * 3) slots -= c->cus / 2;
     }
     slots = std::max<int64_t>(wpb, (slots + wpb - 1) / wpb * wpb);
-    c->waves_per_cu = (int)std::max<int64_t>(1, std::min<int64_t>(32, (slots + c->cus - 1) / c->cus));
+    c->waves_per_cu = (int)std::max<int64_t>(1, std::min<int64_t>(32, (slots + c->cus - 1) / c->cus)) * (c->coop ? 2 : 1);
     uint32_t qcap = queue_capacity > 0 ? next_pow2((uint64_t)queue_capacity) : default_queue_capacity(n);
     if (qcap < (uint32_t)WAVE) qcap = WAVE;
     int r = alloc_slots(c, slots, qcap);
@@ -924,7 +947,7 @@ int arcte_hip_destroy(arcte_hip_ctx *c)
     release_cached(c->contrib_key, c->device); release_cached(c->contrib_val, c->device);
     release_cached(c->contrib_key_sorted, c->device); release_cached(c->contrib_val_sorted, c->device);
     c->contrib_temp.release(); c->run_first.release(); c->run_last.release();
-    c->state.release(); c->slot_epoch.release(); c->warm.release(); c->contrib_key.release(); c->contrib_val.release(); c->centrality.release(); c->ranked_ids.release(); c->node_hot.release(); c->edge_hot.release(); c->edge_in_degree.release(); c->data_f.release(); c->in_degree_f.release(); c->edge_in_degree_f.release(); c->queue.release(); c->sup.release();
+    c->state.release(); c->slot_epoch.release(); c->warm.release(); c->contrib_key.release(); c->contrib_val.release(); c->centrality.release(); c->ranked_ids.release(); c->node_hot.release(); c->edge_hot.release(); c->edge_in_degree.release(); c->data_f.release(); c->in_degree_f.release(); c->edge_in_degree_f.release(); c->queue.release(); c->hqueue.release(); c->sup.release();
     c->seeds_d.release(); c->work_pos.release(); c->out_cnt.release(); c->status.release(); c->nop_d.release();
     c->eps_d.release(); c->out_off.release(); c->dst_off.release(); c->counters.release();
     c->raw.release(); c->rows_final.release(); c->sort_keys.release(); c->sort_iota.release(); c->sort_temp.release(); c->eps_big_pos.release(); c->sort_keys_in.release();
@@ -1054,6 +1077,7 @@ static int run_seeds_impl(arcte_hip_ctx *c, const int64_t *seeds, int64_t nseeds
     c->final_rows = 0;
     for (auto &s : c->stats) s = 0;
     c->candidates = 0;
+    c->split_rows = 0;
     for (auto &m : c->ms) m = 0;
     int r = upload_seeds(c, seeds, nseeds);
     if (r) return r;
@@ -1163,6 +1187,7 @@ static int run_seeds_impl(arcte_hip_ctx *c, const int64_t *seeds, int64_t nseeds
         if (!identity && !(sorted_on_device && launches == 0))
             HIP_TRY(hipMemcpyAsync(c->work_pos.p, work.data(), nwork * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipMemsetAsync(c->counters.p, 0, 8 * sizeof(unsigned long long), c->stream));     // (the contribution cursor [8] runs on)
+        HIP_TRY(hipMemsetAsync(c->counters.p + 9, 0, sizeof(unsigned long long), c->stream));     // split rows
         PushParams P;
         P.g = c->graph();
         P.work_pos = identity ? nullptr : c->work_pos.p;
@@ -1176,6 +1201,8 @@ static int run_seeds_impl(arcte_hip_ctx *c, const int64_t *seeds, int64_t nseeds
         P.state = (void *)c->state.p;
         P.slot_epoch = c->slot_epoch.p;
         P.queue = c->queue.p;
+        P.hqueue = c->hqueue.p;
+        P.coop_min = c->coop_min;
         P.sup = c->sup.p;
         P.qcap = c->qcap;
         P.max_pushes = max_pushes_limit();
@@ -1198,7 +1225,7 @@ static int run_seeds_impl(arcte_hip_ctx *c, const int64_t *seeds, int64_t nseeds
         if (r) return r;
         HIP_TRY(hipEventRecord(c->ev[3], c->stream));
         launches++;
-        unsigned long long cnt8[8];
+        unsigned long long cnt8[10];
         HIP_TRY(hipMemcpyAsync(cnt8, c->counters.p, sizeof(cnt8), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipMemcpyAsync(status_h.data(), c->status.p, nseeds * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipMemcpyAsync(cnt_h.data(), c->out_cnt.p, nseeds * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
@@ -1208,6 +1235,7 @@ static int run_seeds_impl(arcte_hip_ctx *c, const int64_t *seeds, int64_t nseeds
         ms_push += ms;
         for (int i = 0; i < 4; i++) c->stats[i] += (int64_t)cnt8[2 + i];
         c->candidates += (int64_t)cnt8[7];
+        c->split_rows += (int64_t)cnt8[9];
 
         // finished seeds of this launch: their rows are appended to rows_final in caller (position) order
         next.clear();
@@ -1656,8 +1684,8 @@ int arcte_hip_run_counters(arcte_hip_ctx *c, int64_t *out, int n)
 {
     if (!c || !out || n < 0) return fail(ARCTE_HIP_EINVAL, "bad argument");
     if (c->run_nseeds < 0) return fail(ARCTE_HIP_ESTATE, "no completed run on this context");
-    const int64_t all[7] = {c->stats[0], c->stats[1], c->stats[2], c->stats[3], c->stats[4], c->stats[5], c->candidates};
-    for (int i = 0; i < n; i++) out[i] = i < 7 ? all[i] : 0;
+    const int64_t all[8] = {c->stats[0], c->stats[1], c->stats[2], c->stats[3], c->stats[4], c->stats[5], c->candidates, c->split_rows};
+    for (int i = 0; i < n; i++) out[i] = i < 8 ? all[i] : 0;
     return 0;
 }
 
@@ -1720,6 +1748,8 @@ static int similarity_slice_impl(arcte_hip_ctx *c, int64_t seed, double rho, dou
             P.state = (void *)c->state.p;
             P.slot_epoch = c->slot_epoch.p;
             P.queue = c->queue.p;
+        P.hqueue = c->hqueue.p;
+        P.coop_min = c->coop_min;
             P.sup = c->sup.p;
             P.qcap = c->qcap;
             P.max_pushes = max_pushes_limit();

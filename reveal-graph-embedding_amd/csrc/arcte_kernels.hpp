@@ -385,7 +385,7 @@ struct PushParams {
     int32_t *out_cnt;
     int32_t *status;
     int32_t *nop;
-    unsigned long long *stats;   // [0] pushes [1] edges [2] enqueues [3] support [4] failed seeds [5] candidates
+    unsigned long long *stats;   // [0] pushes [1] edges [2] enqueues [3] support [4] failed seeds [5] candidates [7] split rows
     // MODE 2: (node << contrib_shift | seed - contrib_seed_base, s/in_degree) of every support node of every seed of
     // the batch, for the centrality accumulation (the seeds of a batch are a block of ascending node ids)
     uint64_t *contrib_key;
@@ -394,6 +394,9 @@ struct PushParams {
     unsigned long long *contrib_cursor;
     int64_t contrib_seed_base;
     int contrib_shift;
+    // COOP: a second wavefront per seed walks the second half of long rows (see CoopShared)
+    QEntry *hqueue;         // [slots][qcap] staging ring of the helper's enqueues
+    int64_t coop_min;       // rows of at least this many edges are split
 };
 
 // Lane j's double as a wavefront-uniform value (j uniform)
@@ -458,6 +461,25 @@ __global__ void k_centrality_non_seeds(const int64_t *indptr, int64_t n, double 
     if (i < n && indptr[i + 1] == indptr[i]) centrality[i] = 1.0;
 }
 
+// COOP launch shape: one workgroup of TWO wavefronts per seed.  Wavefront 0 (the leader) runs the algorithm exactly as
+// the one-wavefront kernel does; wavefront 1 (the helper) owns nothing: it waits at a barrier and, for a row of
+// coop_min edges or more, walks the row's second half while the leader walks the first.  Exact because the targets of
+// one row are distinct nodes (distinct state entries, distinct LDS values) and each receives one deposit; the helper
+// stages the nodes it would enqueue and the leader appends them behind its own, which is the row's edge order.  What
+// it buys is LDS: the table belongs to the SEED, and half as many seeds share a CU at the same number of wavefronts.
+// All control flow is the leader's: the helper follows commands left in LDS, every barrier is met by both.
+struct CoopShared {
+    unsigned long long seed_wk;     // leader -> helper, per seed: work item, arena cursor at draw time
+    unsigned long long seed_cur;
+    double c, r_self, cand_thr, w_row;  // leader -> helper, per split row
+    int64_t rb, re;
+    int32_t row_cmd, u;
+    int32_t nsup;                   // candidate count while a row is split (both append through it)
+    uint32_t h_cnt;                 // helper -> leader: staged enqueues, support growth, ring overflow
+    int32_t h_first, h_ok;
+};
+constexpr int32_t COOP_ROW = 1, COOP_DONE = 2;
+
 // Registers of one step of the push pipeline: the row data of TILES x 64 edges, and the state gathered for them
 template <typename T, int TILES> struct RowStage {
     bool a[TILES];
@@ -489,22 +511,27 @@ template <typename T, int TILES> struct EntStage {
 // NARROW (float64 only): every row's transition weights are one and the same number (an unweighted graph: 1/out_degree)
 // and every in_degree is exactly representable in float32, so a push streams 10 bytes per edge (index, float in_degree,
 // hot rank) instead of 22 -- the weight comes from the row's first entry, the in_degree widens back to the same double.
-template <int MODE, int VAR, typename T, int TILES, bool HOT, bool NARROW = false>
+template <int MODE, int VAR, typename T, int TILES, bool HOT, bool NARROW = false, bool COOP = false>
 __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
 {
+    static_assert(!COOP || (MODE == 0 && VAR == 0 && HOT && sizeof(T) == 8), "the helper wavefront exists for ARCTE's worker in float64");
     extern __shared__ __attribute__((aligned(16))) unsigned char hot_raw[];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int64_t slot = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave;
+    const int64_t slot = COOP ? (int64_t)blockIdx.x : (int64_t)blockIdx.x * (blockDim.x >> 6) + wave;
+    const bool helper = COOP && wave == 1;
     const GraphDev &g = P.g;
     const GraphValues<T> gv = graph_values<T>(g);
     EntryT<T> *__restrict__ st = reinterpret_cast<EntryT<T> *>(P.state) + slot * g.n;
-    QEntry *__restrict__ q = P.queue + slot * (int64_t)P.qcap;
+    // (the helper's "queue" is its staging ring: the row walk below appends to whatever q, head and tail say)
+    QEntry *__restrict__ q = helper ? P.hqueue + slot * (int64_t)P.qcap : P.queue + slot * (int64_t)P.qcap;
+    const QEntry *__restrict__ hq = COOP ? P.hqueue + slot * (int64_t)P.qcap : nullptr;
     int32_t *__restrict__ sup = P.sup + slot * g.n;
     const uint32_t qmask = P.qcap - 1;
     const T omr = (T)P.one_minus_rho;
     const uint32_t K = HOT ? P.hotK : 0u;
-    T *hot = reinterpret_cast<T *>(hot_raw) + (size_t)wave * K;
+    T *hot = reinterpret_cast<T *>(hot_raw) + (COOP ? (size_t)0 : (size_t)wave * K);
+    CoopShared *S = reinterpret_cast<CoopShared *>(hot_raw + (size_t)K * sizeof(T));      // COOP only: behind the table
     const uint32_t K2 = (HOT && P.warmK2 > K) ? P.warmK2 : K;          // warm ranks: [K, K2)
     WarmT<T> *__restrict__ wm = reinterpret_cast<WarmT<T> *>(P.warm) + slot * (int64_t)P.warmN;   // indexed by rank
     uint32_t epoch = P.slot_epoch[slot];
@@ -513,9 +540,21 @@ __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
     // wave_barrier (convergent, emits nothing) keeps LLVM's jump threading from fusing this
     // lane-0 block with the lane-0 block that ends the previous iteration -- that fusion turned the
     // loop divergent (lanes 1..63 ran ahead without lane 0 and never left it).
+    unsigned long long coop_cur = 0;     // COOP: the arena cursor the leader saw when it drew the seed
     auto next_work = [&]() -> unsigned long long {
         __builtin_amdgcn_wave_barrier();
         unsigned long long w = 0;
+        if (COOP) {
+            if (!helper && lane == 0) {
+                S->seed_wk = atomicAdd(P.work_counter, 1ULL);
+                S->seed_cur = __hip_atomic_load(P.raw_cursor, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __syncthreads();
+            w = bcast_u64(S->seed_wk);
+            coop_cur = bcast_u64(S->seed_cur);
+            __syncthreads();            // both have read: the leader may draw again
+            return w;
+        }
         if (lane == 0) w = atomicAdd(P.work_counter, 1ULL);
         return bcast_u64(w);
     };
@@ -541,10 +580,13 @@ __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
         if (MODE != 1) {
             // the arena is already full: this seed is re-run by the host after the arena is drained
             unsigned long long cur = 0;
-            if (lane == 0) cur = __hip_atomic_load(P.raw_cursor, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            cur = bcast_u64(cur);
+            if (COOP) cur = coop_cur;
+            else {
+                if (lane == 0) cur = __hip_atomic_load(P.raw_cursor, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                cur = bcast_u64(cur);
+            }
             if (cur > P.rawcap) {
-                if (lane == 0) {
+                if (lane == 0 && !helper) {
                     P.status[pos] = ST_OUTPUT_OVERFLOW;
                     P.out_cnt[pos] = 0;
                     P.out_off[pos] = 0;
@@ -555,7 +597,7 @@ __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
             }
         }
         epoch++;                           // every entry of the previous seed is stale from here on
-        if (HOT) {
+        if (HOT && !helper) {
             // s[:] = 0; r[:] = 0 for the on-chip nodes
             for (uint32_t i = lane; i < K; i += WAVE) hot[i] = T(0);
         }
@@ -567,6 +609,7 @@ __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
         int32_t npush = 0;
         unsigned long long nedges = 0;
         bool ok = true, runaway = false;
+        bool coop_row = helper;      // a split row is being walked: candidates are counted in LDS
 
         // row data of one pipeline step: TILES x 64 edges from `base`, clamped to the row's last edge `re - 1`.
         // Every lane issues every load of a step, lanes beyond the row's end at a clamped or dummy address (the
@@ -586,51 +629,10 @@ __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
             }
         };
 
-        // ---- one push of node u (push.py:41-64) followed by the ordered enqueue of
-        //      similarity.py:194-196 / :214-216.  `ru` is r[u] at pop time, `hu` u's hot rank, `du` its in_degree.
-        auto push = [&](int32_t u, uint32_t hu, T du, T ru, int64_t rb, int64_t re, bool do_enqueue) {
-            T c;            // what every neighbour receives per unit of transition weight
-            T r_self;       // r[u] right after the push bookkeeping (what a self-loop lane adds to)
-            // u still on chip: this push is its first, so s[u] == r[u] == ru (ARCTE) or s[u] == 0 (PageRank
-            // flavours); it moves to the HBM state now, where the code below finds it as it finds any other node
-            bool on_chip = false;
-            if (HOT && hu < K) {
-                on_chip = !is_moved(hot[hu]);
-                if (on_chip && lane == 0) {
-                    hot[hu] = hot_moved<T>();
-                    store_lo(st + u, ru, (VAR == 0) ? ru : T(0));
-                    store_hi(st + u, du, epoch);
-                }
-            } else if (HOT && hu < K2) {
-                // the same for a node of the warm table (u was deposited to in this epoch: its warm entry is live)
-                const WarmT<T> e = load_warm(wm + hu);
-                on_chip = warm_live(e.tag, epoch) && !is_moved(e.x);
-                if (on_chip && lane == 0) {
-                    store_warm(wm + hu, hot_moved<T>(), epoch);
-                    store_lo(st + u, ru, (VAR == 0) ? ru : T(0));
-                    store_hi(st + u, du, epoch);
-                }
-            }
-            if (VAR == 0) {
-                c = omr * ru;                                    // push.py:56
-                r_self = T(0);
-                if (lane == 0) st[u].r = T(0);                    // push.py:59
-            } else {
-                const T A = (T)P.rho * ru;                     // push.py:10 / :29
-                if (VAR == 1) { c = omr * ru; r_self = T(0); }                                  // push.py:11,15
-                else { c = omr * (1 - (T)P.lazy) * ru; r_self = omr * (T)P.lazy * (ru); }            // push.py:30-31
-                bool grew = false;
-                if (lane == 0) {
-                    const T s_old = on_chip ? T(0) : st[u].s;   // u is live: it was deposited to, or is the seed
-                    const T s_new = s_old + A;              // push.py:14 / :34
-                    store_lo(st + u, r_self, s_new);             // push.py:15 / :35
-                    grew = s_old == T(0) && s_new != T(0);
-                    if (grew) sup[nsup] = u;                     // s is non-zero exactly at pushed nodes
-                }
-                const int g1 = __popcll(__ballot(grew));
-                nsup += g1;
-                nfirst += g1;
-            }
+        // ---- the scatter of one push over the edges [rb, re) of u's row (push.py:60-64) with the ordered enqueue of
+        //      similarity.py:194-196 / :214-216: c is what every neighbour receives per unit of transition weight, r_self
+        //      r[u] right after the push bookkeeping (what a self-loop lane adds to).
+        auto walk = [&](int32_t u, T c, T r_self, int64_t rb, int64_t re, T w_row, bool do_enqueue) __attribute__((always_inline)) {
             // The row is walked TILES x 64 edges at a time as a three-stage software pipeline: the row data (index,
             // weight, in_degree, hot rank) of step i+2 and the state gathers of step i+1 are in flight while step i
             // is added, stored and enqueued.  Legal because the targets of one row are distinct (CSR columns are
@@ -638,7 +640,6 @@ __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
             // pushes program order holds (the next push's gathers are issued after this push's last store).
             RowStage<T, TILES> Ra, Rb, Rc;
             EntStage<T, TILES> Ea, Eb;
-            const T w_row = (NARROW && re > rb) ? gv.data[rb] : T(0);
             auto load_row = [&](int64_t base, RowStage<T, TILES> &R) { load_row_at(base, re, w_row, R); };
             auto gather = [&](const RowStage<T, TILES> &R, EntStage<T, TILES> &E) {
 #pragma unroll
@@ -713,8 +714,17 @@ __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
                         const T bar = cand_thr * dv;
                         const bool cross = act && (s_new > T(0) && s_new >= bar) && !(s_old > T(0) && s_old >= bar);
                         const uint64_t mc = __ballot(cross);
-                        if (cross) sup[nsup + lane_below(mc)] = v;
-                        nsup += __popcll(mc);
+                        if (COOP && coop_row) {
+                            if (mc) {
+                                int32_t at = 0;
+                                if (lane == 0) at = atomicAdd(&S->nsup, (int32_t)__popcll(mc));
+                                at = __shfl(at, 0, WAVE);
+                                if (cross) sup[at + lane_below(mc)] = v;
+                            }
+                        } else {
+                            if (cross) sup[nsup + lane_below(mc)] = v;
+                            nsup += __popcll(mc);
+                        }
                         nfirst += __popcll(__ballot(act && s_old == T(0) && s_new != T(0)));   // support of s grows
                     }
                     if (!do_enqueue) continue;
@@ -754,11 +764,101 @@ __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
                 gather(Ra, Ea);
                 process(Ra, Ea);
             }
+        };
+
+        // ---- one push of node u (push.py:41-64) followed by the ordered enqueue of
+        //      similarity.py:194-196 / :214-216.  `ru` is r[u] at pop time, `hu` u's hot rank, `du` its in_degree.
+        auto push = [&](int32_t u, uint32_t hu, T du, T ru, int64_t rb, int64_t re, bool do_enqueue) {
+            T c;            // what every neighbour receives per unit of transition weight
+            T r_self;       // r[u] right after the push bookkeeping (what a self-loop lane adds to)
+            // u still on chip: this push is its first, so s[u] == r[u] == ru (ARCTE) or s[u] == 0 (PageRank
+            // flavours); it moves to the HBM state now, where the code below finds it as it finds any other node
+            bool on_chip = false;
+            if (HOT && hu < K) {
+                on_chip = !is_moved(hot[hu]);
+                if (on_chip && lane == 0) {
+                    hot[hu] = hot_moved<T>();
+                    store_lo(st + u, ru, (VAR == 0) ? ru : T(0));
+                    store_hi(st + u, du, epoch);
+                }
+            } else if (HOT && hu < K2) {
+                // the same for a node of the warm table (u was deposited to in this epoch: its warm entry is live)
+                const WarmT<T> e = load_warm(wm + hu);
+                on_chip = warm_live(e.tag, epoch) && !is_moved(e.x);
+                if (on_chip && lane == 0) {
+                    store_warm(wm + hu, hot_moved<T>(), epoch);
+                    store_lo(st + u, ru, (VAR == 0) ? ru : T(0));
+                    store_hi(st + u, du, epoch);
+                }
+            }
+            if (VAR == 0) {
+                c = omr * ru;                                    // push.py:56
+                r_self = T(0);
+                if (lane == 0) st[u].r = T(0);                    // push.py:59
+            } else {
+                const T A = (T)P.rho * ru;                     // push.py:10 / :29
+                if (VAR == 1) { c = omr * ru; r_self = T(0); }                                  // push.py:11,15
+                else { c = omr * (1 - (T)P.lazy) * ru; r_self = omr * (T)P.lazy * (ru); }            // push.py:30-31
+                bool grew = false;
+                if (lane == 0) {
+                    const T s_old = on_chip ? T(0) : st[u].s;   // u is live: it was deposited to, or is the seed
+                    const T s_new = s_old + A;              // push.py:14 / :34
+                    store_lo(st + u, r_self, s_new);             // push.py:15 / :35
+                    grew = s_old == T(0) && s_new != T(0);
+                    if (grew) sup[nsup] = u;                     // s is non-zero exactly at pushed nodes
+                }
+                const int g1 = __popcll(__ballot(grew));
+                nsup += g1;
+                nfirst += g1;
+            }
+            const T w_row = (NARROW && re > rb) ? gv.data[rb] : T(0);
+            if (COOP && re - rb >= P.coop_min) {
+                // split: the helper takes [mid, re), in whole steps
+                constexpr int64_t STEP = TILES * WAVE;
+                const int64_t mid = rb + ((re - rb) / 2 + STEP - 1) / STEP * STEP;
+                if (lane == 0) {
+                    S->u = u; S->c = (double)c; S->r_self = (double)r_self; S->cand_thr = (double)cand_thr; S->w_row = (double)w_row;
+                    S->rb = mid; S->re = re; S->nsup = nsup; S->row_cmd = COOP_ROW;
+                    atomicAdd(&P.stats[7], 1ULL);                  // split rows
+                }
+                coop_row = true;
+                __syncthreads();                                   // (A) the helper starts
+                walk(u, c, r_self, rb, mid, w_row, do_enqueue);
+                __syncthreads();                                   // (B) both halves are stored
+                coop_row = false;
+                nsup = S->nsup;
+                nfirst += S->h_first;
+                if (!S->h_ok) ok = false;
+                const uint32_t hcnt = S->h_cnt;
+                if (ok && hcnt) {
+                    if (tail - head + hcnt > P.qcap) ok = false;
+                    else {
+                        for (uint32_t i = lane; i < hcnt; i += WAVE) q[(tail + i) & qmask] = hq[i];
+                        tail += hcnt;
+                    }
+                }
+            } else {
+                walk(u, c, r_self, rb, re, w_row, do_enqueue);
+            }
             npush++;
             nedges += (unsigned long long)(re - rb);
             if (npush >= P.max_pushes) { ok = false; runaway = true; }
         };
 
+        if (helper) {
+            // serve the split rows of this seed until the leader is done with it
+            for (;;) {
+                __syncthreads();                                   // (A)
+                if (S->row_cmd == COOP_DONE) break;
+                head = 0; tail = 0; nfirst = 0; ok = true;
+                cand_thr = (T)S->cand_thr;
+                walk((int32_t)bcast_u64((uint64_t)(uint32_t)S->u), (T)S->c, (T)S->r_self, (int64_t)bcast_u64((uint64_t)S->rb),
+                     (int64_t)bcast_u64((uint64_t)S->re), (T)S->w_row, true);
+                if (lane == 0) { S->h_cnt = tail; S->h_first = nfirst; S->h_ok = ok ? 1 : 0; }
+                __syncthreads();                                   // (B)
+            }
+            continue;
+        }
         // ---- similarity.py:176-192: s[seed] = r[seed] = 1, one unconditional push
         const int64_t seed_b = g.indptr[seed], seed_e = g.indptr[seed + 1];
         const T seed_d = gv.in_degree[seed];
@@ -985,8 +1085,12 @@ __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
                 atomicAdd(&P.stats[4], 1ULL);
             }
         }
+        if (COOP) {
+            if (lane == 0) S->row_cmd = COOP_DONE;
+            __syncthreads();                                       // (A): releases the helper into the next seed
+        }
     }
-    if (lane == 0) P.slot_epoch[slot] = epoch;
+    if (lane == 0 && !helper) P.slot_epoch[slot] = epoch;
 }
 
 // copy per-seed segments src[src_off[p] .. +cnt[p]) -> dst[dst_off[p] ..), one wavefront per segment;

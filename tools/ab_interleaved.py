@@ -16,7 +16,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from hot_sweep import load_graph, result_hash
 from reveal_graph_embedding_amd import _native
 
-KNOBS = ("WAVES_PER_CU", "HOT", "WARM", "NARROW", "TILES", "LDS_RESERVE_KB", "WAVES_PER_BLOCK")
+KNOBS = ("WAVES_PER_CU", "HOT", "WARM", "NARROW", "TILES", "LDS_RESERVE_KB", "WAVES_PER_BLOCK", "COOP", "COOP_MIN")
 
 
 def main():
