@@ -209,6 +209,7 @@ struct arcte_hip_ctx {
     int coop = 0;                // a helper wavefront per seed walks the second half of long rows (CoopShared)
     int64_t coop_min = 512;      // rows of at least this many edges are split
     DevBuf<QEntry> hqueue;       // [slots][qcap] the helpers' staging rings
+    DevBuf<unsigned long long> prof;   // ARCTE_HIP_PROFILE=1: phase ticks of the push kernel (PushParams::prof)
     int waves_per_cu = 0;        // resident wavefronts per CU the slot count was sized for
     int tiles = 2;               // 64-edge tiles per push iteration
     int narrow = 0;              // uniform row weights + float32-exact in_degrees: the push streams 10 bytes per edge
@@ -370,6 +371,8 @@ int launch_seeds_v(arcte_hip_ctx *c, PushParams P, int64_t nwork)
     const size_t lds = (size_t)wpb * P.hotK * sizeof(T);
     if (P.hotK == 0) return launch_with_lds(k_arcte_seeds<MODE, VAR, T, 2, false>, blocks, wpb * WAVE, lds, c->stream, P);
     if constexpr (std::is_same<T, double>::value && MODE == 0 && VAR == 0) {
+        if (c->prof.p && c->narrow && !c->coop && c->tiles == 2)
+            return launch_with_lds(k_arcte_seeds<0, 0, double, 2, true, true, false, true>, blocks, wpb * WAVE, lds, c->stream, P);
         if (c->coop) {
             // one workgroup of two wavefronts per seed: leader + helper
             const int seeds_in_flight = (int)std::min<int64_t>(c->slots, std::max<int64_t>(nwork, 1));
@@ -947,7 +950,7 @@ int arcte_hip_destroy(arcte_hip_ctx *c)
     release_cached(c->contrib_key, c->device); release_cached(c->contrib_val, c->device);
     release_cached(c->contrib_key_sorted, c->device); release_cached(c->contrib_val_sorted, c->device);
     c->contrib_temp.release(); c->run_first.release(); c->run_last.release();
-    c->state.release(); c->slot_epoch.release(); c->warm.release(); c->contrib_key.release(); c->contrib_val.release(); c->centrality.release(); c->ranked_ids.release(); c->node_hot.release(); c->edge_hot.release(); c->edge_in_degree.release(); c->data_f.release(); c->in_degree_f.release(); c->edge_in_degree_f.release(); c->queue.release(); c->hqueue.release(); c->sup.release();
+    c->state.release(); c->slot_epoch.release(); c->warm.release(); c->contrib_key.release(); c->contrib_val.release(); c->centrality.release(); c->ranked_ids.release(); c->node_hot.release(); c->edge_hot.release(); c->edge_in_degree.release(); c->data_f.release(); c->in_degree_f.release(); c->edge_in_degree_f.release(); c->queue.release(); c->hqueue.release(); c->prof.release(); c->sup.release();
     c->seeds_d.release(); c->work_pos.release(); c->out_cnt.release(); c->status.release(); c->nop_d.release();
     c->eps_d.release(); c->out_off.release(); c->dst_off.release(); c->counters.release();
     c->raw.release(); c->rows_final.release(); c->sort_keys.release(); c->sort_iota.release(); c->sort_temp.release(); c->eps_big_pos.release(); c->sort_keys_in.release();
@@ -1181,6 +1184,10 @@ static int run_seeds_impl(arcte_hip_ctx *c, const int64_t *seeds, int64_t nseeds
     bool identity = false;
     int64_t final_used = 0;
     double ms_push = 0, ms_compact = 0;
+    if (env_int("ARCTE_HIP_PROFILE", 0) != 0) {
+        if (!c->prof.p) HIP_TRY(c->prof.alloc(16));
+        HIP_TRY(hipMemsetAsync(c->prof.p, 0, c->prof.bytes(), c->stream));
+    } else c->prof.release();
     int launches = 0;
     while (!work.empty()) {
         const int64_t nwork = (int64_t)work.size();
@@ -1203,6 +1210,7 @@ static int run_seeds_impl(arcte_hip_ctx *c, const int64_t *seeds, int64_t nseeds
         P.queue = c->queue.p;
         P.hqueue = c->hqueue.p;
         P.coop_min = c->coop_min;
+        P.prof = c->prof.p;
         P.sup = c->sup.p;
         P.qcap = c->qcap;
         P.max_pushes = max_pushes_limit();
@@ -1346,6 +1354,14 @@ static int run_seeds_impl(arcte_hip_ctx *c, const int64_t *seeds, int64_t nseeds
     c->ms[1] = ms_push;
     c->ms[2] = ms_compact;
     c->ms[3] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (c->prof.p) {
+        // ARCTE_HIP_PROFILE=1 (a study aid, tools/phase_profile.py): s_memtime ticks per phase, summed over wavefronts
+        unsigned long long p[10];
+        HIP_TRY(hipMemcpy(p, c->prof.p, sizeof(p), hipMemcpyDeviceToHost));
+        fprintf(stderr, "[arcte_hip profile] ticks: setup %llu pop_batches %llu short_pushes %llu long_pushes %llu pop_loop_rest %llu extraction %llu draw %llu | "
+                        "counts: short_pushes %llu long_pushes %llu pop_batches %llu | push_ms %.3f slots %lld\n",
+                p[0], p[1], p[2], p[3], p[4], p[5], p[9], p[6], p[7], p[8], ms_push, (long long)c->slots);
+    }
     return 0;
 }
 
@@ -1750,6 +1766,7 @@ static int similarity_slice_impl(arcte_hip_ctx *c, int64_t seed, double rho, dou
             P.queue = c->queue.p;
         P.hqueue = c->hqueue.p;
         P.coop_min = c->coop_min;
+        P.prof = c->prof.p;
             P.sup = c->sup.p;
             P.qcap = c->qcap;
             P.max_pushes = max_pushes_limit();

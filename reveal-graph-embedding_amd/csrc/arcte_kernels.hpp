@@ -397,6 +397,10 @@ struct PushParams {
     // COOP: a second wavefront per seed walks the second half of long rows (see CoopShared)
     QEntry *hqueue;         // [slots][qcap] staging ring of the helper's enqueues
     int64_t coop_min;       // rows of at least this many edges are split
+    // PROF: where the wavefronts' time goes (s_memtime ticks summed over wavefronts): [0] seed set-up, [1] pop batches
+    // (queue entries, r, row bounds), [2] pushes of rows that fit one step, [3] longer rows, [4] the rest of the pop loop
+    // (re-reads, re-tests), [5] extraction, [6] short pushes, [7] long pushes, [8] pop batches, [9] drawing work
+    unsigned long long *prof;
 };
 
 // Lane j's double as a wavefront-uniform value (j uniform)
@@ -511,9 +515,11 @@ template <typename T, int TILES> struct EntStage {
 // NARROW (float64 only): every row's transition weights are one and the same number (an unweighted graph: 1/out_degree)
 // and every in_degree is exactly representable in float32, so a push streams 10 bytes per edge (index, float in_degree,
 // hot rank) instead of 22 -- the weight comes from the row's first entry, the in_degree widens back to the same double.
-template <int MODE, int VAR, typename T, int TILES, bool HOT, bool NARROW = false, bool COOP = false>
+template <int MODE, int VAR, typename T, int TILES, bool HOT, bool NARROW = false, bool COOP = false, bool PROF = false>
 __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
 {
+    unsigned long long prof[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    auto tick = [&]() -> unsigned long long { return PROF ? (unsigned long long)__builtin_amdgcn_s_memtime() : 0ULL; };
     static_assert(!COOP || (MODE == 0 && VAR == 0 && HOT && sizeof(T) == 8), "the helper wavefront exists for ARCTE's worker in float64");
     extern __shared__ __attribute__((aligned(16))) unsigned char hot_raw[];
     const int lane = threadIdx.x & 63;
@@ -572,8 +578,10 @@ __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
     // (the extra bound is insurance only: a wave can draw at most nwork items, so a loop that ever ran past that
     //  would be a compiler-induced divergence like the one described above, and must still terminate)
     unsigned long long drawn = 0;
+    unsigned long long t_mark = tick();
     for (unsigned long long wk = next_work(); wk < (unsigned long long)P.nwork && drawn <= (unsigned long long)P.nwork;
          wk = next_work(), drawn++) {
+        if (PROF) { const unsigned long long t = tick(); prof[9] += t - t_mark; t_mark = t; }
         const int32_t pos = P.work_pos ? P.work_pos[wk] : (int32_t)wk;
         const int32_t seed = P.seeds[pos];
         const T eps = (T)P.eps[pos];
@@ -769,6 +777,7 @@ __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
         // ---- one push of node u (push.py:41-64) followed by the ordered enqueue of
         //      similarity.py:194-196 / :214-216.  `ru` is r[u] at pop time, `hu` u's hot rank, `du` its in_degree.
         auto push = [&](int32_t u, uint32_t hu, T du, T ru, int64_t rb, int64_t re, bool do_enqueue) {
+            const unsigned long long t_push = tick();
             T c;            // what every neighbour receives per unit of transition weight
             T r_self;       // r[u] right after the push bookkeeping (what a self-loop lane adds to)
             // u still on chip: this push is its first, so s[u] == r[u] == ru (ARCTE) or s[u] == 0 (PageRank
@@ -843,6 +852,14 @@ __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
             npush++;
             nedges += (unsigned long long)(re - rb);
             if (npush >= P.max_pushes) { ok = false; runaway = true; }
+            if (PROF) {
+                // (the time of a push is taken out of the phase it interrupts: t_mark moves forward by it)
+                const unsigned long long dt = tick() - t_push;
+                const bool is_long = re - rb > (int64_t)TILES * WAVE;
+                prof[is_long ? 3 : 2] += dt;
+                prof[is_long ? 7 : 6] += 1;
+                t_mark += dt;
+            }
         };
 
         if (helper) {
@@ -890,6 +907,7 @@ __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
             cand_thr = wave_min_real<T>(lb) * cand_margin<T>();
         }
         // (PageRank flavours: s is non-zero only at pushed nodes; the candidate list is the pushed nodes)
+        if (PROF) { const unsigned long long t = tick(); prof[0] += t - t_mark; t_mark = t; }
         push(seed, HOT_NONE, seed_d, T(1), seed_b, seed_e, true);
         if (VAR == 2) {
             // similarity.py:108-116: re-push the seed while it stays above the threshold, no enqueue
@@ -924,6 +942,13 @@ __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
             head += bn;    // the batch lives in registers from here on
             int consumed = 0;
             bool pass = valid && (r_l / d_l >= eps);                                  // similarity.py:204
+            if (PROF) {
+                // (the ballot makes the wavefront wait for the loads of the batch)
+                const unsigned long long any = __ballot(pass);
+                asm volatile("" ::"s"(any));
+                const unsigned long long t = tick();
+                prof[1] += t - t_mark; t_mark = t; prof[8] += 1;
+            }
             for (;;) {
                 const uint64_t m = __ballot(pass && lane >= consumed);
                 if (m == 0) break;
@@ -960,6 +985,7 @@ __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
             }
         }
 
+        if (PROF) { const unsigned long long t = tick(); prof[4] += t - t_mark; t_mark = t; }
         // ---- arcte.py:352-376: degree-normalise, threshold = min over the closed neighbourhood,
         //      select everything at or above it, emit iff larger than the base community.
         //      One pass over the candidate list: selected nodes are compacted in place, then copied.
@@ -1089,8 +1115,13 @@ __global__ __launch_bounds__(BLOCK) void k_arcte_seeds(PushParams P)
             if (lane == 0) S->row_cmd = COOP_DONE;
             __syncthreads();                                       // (A): releases the helper into the next seed
         }
+        if (PROF) { const unsigned long long t = tick(); prof[5] += t - t_mark; t_mark = t; }
     }
     if (lane == 0 && !helper) P.slot_epoch[slot] = epoch;
+    if (PROF && lane == 0 && P.prof) {
+#pragma unroll
+        for (int k = 0; k < 10; k++) atomicAdd(P.prof + k, prof[k]);
+    }
 }
 
 // copy per-seed segments src[src_off[p] .. +cnt[p]) -> dst[dst_off[p] ..), one wavefront per segment;
