@@ -198,9 +198,11 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     push_ms = 0.0
+    step_kernel_ms = []
     for _ in range(args.steps):
         step()
-        push_ms += ctx.timing()["push_ms"]
+        step_kernel_ms.append(ctx.timing()["push_ms"])
+        push_ms += step_kernel_ms[-1]
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -314,6 +316,7 @@ def main():
                                          "frac_of_read": achieved / stream_read if stream_read > 0 else None,
                                          "how": "arcte_hip_stream_bandwidth: 16 B/lane sweep over 4 GiB on this box, best of 3"},
                 "algorithmic_bytes_per_launch": alg, "kernel_ms_per_launch": kernel_ms,
+                "kernel_ms_each_launch": [round(x, 3) for x in step_kernel_ms],
             },
         }
         if args.variant != "arcte":
