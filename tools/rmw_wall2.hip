@@ -101,7 +101,12 @@ int main(int argc, char **argv)
     double *sink;
     double2 *st;
     const uint64_t stream_elems = ((size_t)4 << 30) / 16;      // 4 GB of rows to stream
-    if (hipMalloc(&tab, bytes) != hipSuccess || hipMalloc(&sink, 8) != hipSuccess || hipMalloc(&st, stream_elems * 16) != hipSuccess) {
+    // RMW_ALLOC=contiguous: physically contiguous table (hipDeviceMallocContiguous) -- does the random-access rate depend
+    // on how the allocation is backed?
+    const char *how = getenv("RMW_ALLOC");
+    hipError_t te = (how && how[0] == 'c') ? hipExtMallocWithFlags((void **)&tab, bytes, hipDeviceMallocContiguous) : hipMalloc(&tab, bytes);
+    if (te != hipSuccess) { fprintf(stderr, "table allocation failed: %s\n", hipGetErrorString(te)); return 1; }
+    if (hipMalloc(&sink, 8) != hipSuccess || hipMalloc(&st, stream_elems * 16) != hipSuccess) {
         fprintf(stderr, "alloc failed\n");
         return 1;
     }
