@@ -25,7 +25,6 @@ Fixture layout (one .npz per graph, see tests/test_oracle_golden.py for the read
   worker_*         arcte_worker() output for the sampled seeds (arcte.py:279)
 """
 import hashlib
-import io
 import os
 import subprocess
 import sys

@@ -4,7 +4,7 @@ contributions are folded in seed order, as the reference adds them), normalised 
 import numpy as np
 import pytest
 
-from conftest import assert_same_sparse
+from conftest import GOLDEN  # noqa: F401  (conftest puts the repo root on sys.path)
 from oracle import oracle
 from test_centrality_weighting_cpu import CENTRALITY_GRAPHS, assert_close_sparse, load_centrality
 

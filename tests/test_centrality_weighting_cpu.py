@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 import scipy.sparse as sparse
 
-from conftest import GOLDEN, assert_same_sparse, load_golden
+from conftest import GOLDEN, load_golden
 from oracle import oracle
 
 CENTRALITY_GRAPHS = ["ba300", "weighted", "selfloop", "grid25", "ws1000", "rmat2000", "directed"]

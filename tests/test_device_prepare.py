@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import scipy.sparse as sparse
 
-from conftest import GOLDEN_GRAPHS, assert_same_sparse, load_golden
+from conftest import assert_same_sparse, load_golden
 from oracle import oracle
 
 pytestmark = pytest.mark.gpu

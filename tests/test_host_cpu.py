@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import scipy.sparse as sparse
 
-from conftest import ROOT, assert_same_sparse
+from conftest import ROOT
 
 from reveal_graph_embedding_amd import _native
 from reveal_graph_embedding_amd.embedding.arcte.arcte import parallel_chunks, roundrobin_chunks, seed_nodes

@@ -1,4 +1,4 @@
-import time, sys, numpy as np
+import sys
 sys.path.insert(0, ".")
 from reveal_graph_embedding_amd import _native
 from reveal_graph_embedding_amd.synthetic import rmat_graph
