@@ -122,6 +122,8 @@ def main():
                          "SHA-256 of its canonical CSR (tests compare it with the reference's own run)")
     args = ap.parse_args()
 
+    # (dmabuf IPC is the only kind the host driver of this pool supports: RCCL's peer buffers need it)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
