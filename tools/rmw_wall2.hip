@@ -104,8 +104,36 @@ int main(int argc, char **argv)
     // RMW_ALLOC=contiguous: physically contiguous table (hipDeviceMallocContiguous) -- does the random-access rate depend
     // on how the allocation is backed?
     const char *how = getenv("RMW_ALLOC");
-    hipError_t te = (how && how[0] == 'c') ? hipExtMallocWithFlags((void **)&tab, bytes, hipDeviceMallocContiguous) : hipMalloc(&tab, bytes);
+    hipError_t te = hipSuccess;
+    if (how && how[0] == 'v') {
+        // RMW_ALLOC=vmm[:ALIGN_MB[:CHUNK_MB]]: a virtual range of chosen alignment, backed by physical chunks of chosen size
+        size_t align_mb = 1024, chunk_mb = 1024;
+        sscanf(how, "vmm:%zu:%zu", &align_mb, &chunk_mb);
+        hipMemAllocationProp prop = {};
+        prop.type = hipMemAllocationTypePinned;
+        prop.location.type = hipMemLocationTypeDevice;
+        prop.location.id = 0;
+        size_t gran = 0;
+        te = hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended);
+        const size_t chunk = (chunk_mb << 20) / gran * gran;
+        const size_t total = (bytes + chunk - 1) / chunk * chunk;
+        void *va = nullptr;
+        if (te == hipSuccess) te = hipMemAddressReserve(&va, total, align_mb << 20, nullptr, 0);
+        for (size_t off = 0; te == hipSuccess && off < total; off += chunk) {
+            hipMemGenericAllocationHandle_t h;
+            te = hipMemCreate(&h, chunk, &prop, 0);
+            if (te == hipSuccess) te = hipMemMap((char *)va + off, chunk, 0, h, 0);
+        }
+        hipMemAccessDesc acc = {};
+        acc.location = prop.location;
+        acc.flags = hipMemAccessFlagsProtReadWrite;
+        if (te == hipSuccess) te = hipMemSetAccess(va, total, &acc, 1);
+        tab = (char *)va;
+        fprintf(stderr, "vmm: granularity %zu, chunk %zu MB, va %p\n", gran, chunk >> 20, va);
+    } else if (how && how[0] == 'c') te = hipExtMallocWithFlags((void **)&tab, bytes, hipDeviceMallocContiguous);
+    else te = hipMalloc(&tab, bytes);
     if (te != hipSuccess) { fprintf(stderr, "table allocation failed: %s\n", hipGetErrorString(te)); return 1; }
+    fprintf(stderr, "table at %p\n", (void *)tab);
     if (hipMalloc(&sink, 8) != hipSuccess || hipMalloc(&st, stream_elems * 16) != hipSuccess) {
         fprintf(stderr, "alloc failed\n");
         return 1;
