@@ -108,6 +108,9 @@ def main():
     ap.add_argument("--rho", type=float, default=0.1)
     ap.add_argument("--epsilon", type=float, default=1e-5)
     ap.add_argument("--slots", type=int, default=0)
+    ap.add_argument("--placement-tries", type=int, default=3,
+                    help="contexts drawn before the run, the fastest on a calibration sample is kept (the kernel's duration "
+                         "belongs to the allocation of the slot buffers: DESIGN.md section 5); 1 = take the first")
     ap.add_argument("--gather", choices=["rows", "counts"], default="rows",
                     help="N>1: what rank 0 collects per step (rows = the full result)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (0 = skip)")
@@ -162,7 +165,19 @@ def main():
     adjacency = load_graph(args.nodes, args.edges, 0, local_rank, barrier)
     nnz = int(adjacency.nnz)
     w_indptr, w_indices = adjacency.indptr, adjacency.indices          # pattern of W = pattern of A (--verify)
-    ctx = _native.Context.from_adjacency(adjacency.indptr, adjacency.indices, adjacency.data, device=gpu, n_slots=args.slots)
+    def make_context():
+        return _native.Context.from_adjacency(adjacency.indptr, adjacency.indices, adjacency.data, device=gpu, n_slots=args.slots)
+
+    def calibrate(c):
+        # kernel time of every 16th seed of this rank's shard, best of two (all of this happens before the warm-up)
+        sample = shard_seeds(c.seed_list(), args.shards, rank)[::16]
+        best = float("inf")
+        for _ in range(2):
+            c.run_seeds(sample, args.rho, args.epsilon, use_effective_epsilon=True)
+            best = min(best, c.timing()["push_ms"])
+        return best
+
+    ctx, placement_ms = _native.fastest_context(make_context, calibrate, tries=args.placement_tries)
     del adjacency
     seeds = ctx.seed_list()
     shard = shard_seeds(seeds, args.shards, rank)
@@ -300,6 +315,7 @@ def main():
                 "hot_values_per_wave": info["hot_values_per_wave"], "narrow_rows": info["narrow_rows"],
                 "warm_end_rank": info["warm_end_rank"],
                 "kernel_source_id": kernel_source_id(),
+                "placement_tries": len(placement_ms), "placement_calibration_ms": [round(x, 2) for x in placement_ms],
                 "emitted_rows_rank0": int(total_rows), "emitted_rows_all_ranks": emitted_all, "merged_sha256": merged_sha,
                 "gathered_rows_rank0": int(gathered_rows),
                 "per_seed": {k: st[k] / max(shard.size, 1) for k in ("pushes", "edges", "enqueues", "support")},

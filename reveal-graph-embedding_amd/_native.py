@@ -135,6 +135,38 @@ def stream_bandwidth(device=0, nbytes=4 << 30):
     return rd.value, cp.value
 
 
+def fastest_context(make, calibrate, tries=3):
+    """Draw `tries` contexts and keep the fastest.
+
+    The duration of the propagation kernel belongs to the ALLOCATION a context's slot buffers happen to get: contexts on
+    the same buffers repeat to 0.5 %, fresh allocations differ by up to 20 % (DESIGN.md section 5,
+    profiles/r02/context_lottery_1m.txt).  A long-running service pays for a good draw once: `make()` builds a context
+    (they are alive at the same time, so they cannot be handed the same memory), `calibrate(ctx)` returns a duration
+    for it (e.g. the kernel time of a sample of seeds); the slower contexts are closed and their memory returned.
+    Returns (context, [calibration results in draw order])."""
+    drawn, results = [], []
+    try:
+        for _ in range(max(1, int(tries))):
+            try:
+                ctx = make()
+            except ArcteHipError:
+                if drawn:                     # no room for another one: choose among those we have
+                    break
+                raise
+            drawn.append(ctx)
+            results.append(calibrate(ctx))
+        best = min(range(len(drawn)), key=lambda k: results[k])
+        keep = drawn[best]
+        drawn[best] = None
+        return keep, results
+    finally:
+        for ctx in drawn:
+            if ctx is not None:
+                ctx.close()
+        if len(results) > 1:
+            trim()
+
+
 class Context:
     """Device-resident transition matrix + propagation slots on one GPU."""
 

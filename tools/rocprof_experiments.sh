@@ -7,8 +7,8 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof_exp
 rm -rf $OUT && mkdir -p $OUT
-ARGS="$R/bench.py --shards 8 --steps 2 --warmup 1 --cpu-seconds 0"
-python3 $R/bench.py --shards 8 --steps 1 --warmup 0 --cpu-seconds 0 > /dev/null 2>&1   # graph cache
+ARGS="$R/bench.py --shards 8 --steps 2 --warmup 1 --cpu-seconds 0 --placement-tries 1"
+python3 $R/bench.py --shards 8 --steps 1 --warmup 0 --cpu-seconds 0 --placement-tries 1 > /dev/null 2>&1   # graph cache
 arm() {  # name, env assignments...
   name=$1; shift
   for kv in "$@"; do export "$kv"; done
