@@ -428,3 +428,27 @@ def test_slot_buffers_are_reused_across_contexts_and_trimmed():
         colptr, rows, nop = ctx.fetch(want_nop=True)
     assert all(np.array_equal(a, b) for a, b in zip(results[0], (colptr, rows, nop)))
     _native.trim()
+
+
+@pytest.mark.gpu
+def test_fastest_context_returns_a_working_context():
+    """Several contexts alive at once, one kept: the kept one computes what any context computes."""
+    adjacency = rmat_graph(20000, 200000, seed=1)
+
+    def make():
+        return _native.Context.from_adjacency(adjacency.indptr, adjacency.indices, adjacency.data, n_slots=64)
+
+    def calibrate(ctx):
+        ctx.run_seeds(ctx.seed_list()[::4], 0.1, 1e-5)
+        return ctx.timing()["push_ms"]
+
+    ctx, results = _native.fastest_context(make, calibrate, tries=3)
+    with ctx:
+        assert len(results) == 3 and all(r > 0 for r in results)
+        seeds = np.sort(ctx.seed_list())
+        ctx.run_seeds(seeds, 0.1, 1e-5)
+        got = ctx.fetch(want_nop=True)
+    with make() as ref:
+        ref.run_seeds(seeds, 0.1, 1e-5)
+        want = ref.fetch(want_nop=True)
+    assert all(np.array_equal(a, b) for a, b in zip(got, want))

@@ -91,3 +91,34 @@ def test_background_ones_cover_every_entry():
         out = _OnesInBackground(size, threads=4).result()
         assert out.dtype == np.float64 and out.shape == (size,)
         assert np.all(out == 1.0)
+
+
+def test_fastest_context_keeps_the_best_draw_and_closes_the_rest():
+    from reveal_graph_embedding_amd import _native
+
+    class Fake:
+        def __init__(self, speed):
+            self.speed, self.closed = speed, False
+
+        def close(self):
+            self.closed = True
+
+    speeds = iter([3.0, 1.0, 2.0])
+    made = []
+
+    def make():
+        made.append(Fake(next(speeds)))
+        return made[-1]
+
+    best, results = _native.fastest_context(make, lambda c: c.speed, tries=3)
+    assert results == [3.0, 1.0, 2.0] and best is made[1]
+    assert [c.closed for c in made] == [True, False, True]
+    # a draw that fails for lack of memory ends the drawing; the first failure is the caller's
+    def make_then_fail():
+        if made_b:
+            raise _native.ArcteHipError(-3, "out of memory")
+        made_b.append(Fake(5.0))
+        return made_b[-1]
+    made_b = []
+    best, results = _native.fastest_context(make_then_fail, lambda c: c.speed, tries=3)
+    assert best is made_b[0] and results == [5.0] and not best.closed
