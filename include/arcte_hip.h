@@ -316,6 +316,16 @@ int arcte_hip_launch_occupancy(arcte_hip_ctx *ctx, int *workgroups_per_cu);
  * warm table (nodes ranked between [5] and [9] keep their state in a compact per-slot array; 0 = off). */
 int arcte_hip_info(arcte_hip_ctx *ctx, int64_t info[10]);
 
+/* Where the per-seed state lives (no counterpart in the reference, whose s and r are two dense numpy vectors per
+ * worker, arcte.py:325-326, re-zeroed per seed, :337-338).  info[0] 1: line state (nodes named by rank, one float64
+ * per node and slot in strided 64-byte lines, touched-line bitmap in LDS, pushed nodes in a compact {r, s} array),
+ * 0: dense 32-byte entries with epoch tags; [1] lines per slot (M: a slot holds 8 M values); [2] entries of the
+ * pushed-state array per slot; [3] entries of the candidate list per slot; [4] bytes of slot scratch held;
+ * [5] bytes of LDS the bitmap takes per wavefront; [6] bytes of LDS a wavefront may claim; [7] reserved;
+ * of the last run: [8] updates of on-chip values, [9] blind whole-line writes (first touch of a line),
+ * [10] read-modify-writes of a line, [11] updates of pushed nodes. */
+int arcte_hip_state_info(arcte_hip_ctx *ctx, int64_t info[12]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -58,6 +58,7 @@ SIGNATURES = {
     "arcte_hip_set_float32": (C.c_int, [C.c_void_p, C.c_int]),
     "arcte_hip_stream_bandwidth": (C.c_int, [C.c_int, C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "arcte_hip_info": (C.c_int, [C.c_void_p, _i64p]),
+    "arcte_hip_state_info": (C.c_int, [C.c_void_p, _i64p]),
     "arcte_hip_launch_occupancy": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "arcte_hip_features_from_result": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
     "arcte_hip_features_upload": (C.c_int, [C.c_int, C.c_int64, C.c_int64, C.c_int64, _i64p, _i32p, _f64p, C.POINTER(C.c_void_p)]),
@@ -358,6 +359,15 @@ class Context:
         return dict(slots=int(i[0]), queue_capacity=int(i[1]), device_bytes=int(i[2]), compute_units=int(i[3]),
                     waves_per_workgroup=int(i[4]), hot_values_per_wave=int(i[5]), tiles=int(i[6]),
                     waves_per_cu=int(i[7]), narrow_rows=int(i[8]), warm_end_rank=int(i[9]))
+
+    def state_info(self):
+        """Where the per-seed state lives and, of the last run, how its updates were served (arcte_hip_state_info)."""
+        i = np.zeros(12, dtype=np.int64)
+        _check(lib().arcte_hip_state_info(self._h, i))
+        return dict(line_state=int(i[0]), lines_per_slot=int(i[1]), pushed_capacity=int(i[2]), candidate_capacity=int(i[3]),
+                    slot_bytes=int(i[4]), bitmap_lds_bytes=int(i[5]), lds_bytes_per_wave=int(i[6]),
+                    lds_updates=int(i[8]), blind_line_writes=int(i[9]), line_read_modify_writes=int(i[10]),
+                    pushed_node_updates=int(i[11]))
 
     def launch_occupancy(self):
         """Workgroups of the propagation kernel per CU according to the runtime's occupancy query (diagnostic)."""

@@ -33,6 +33,7 @@
 #include "arcte_hip.h"
 
 #include "arcte_kernels.hpp"
+#include "arcte_lines.hpp"
 #include "arcte_prepare.hpp"
 #include "arcte_features.hpp"
 
@@ -215,6 +216,23 @@ struct arcte_hip_ctx {
     int narrow = 0;              // uniform row weights + float32-exact in_degrees: the push streams 10 bytes per edge
     uint64_t seeds_since_clear = 0;
     std::vector<int32_t> row_len;   // host copy of the row lengths: the work order is heaviest seed first
+    // line state (arcte_lines.hpp): nodes named by rank, one float64 per node and slot in strided 64-byte lines, a
+    // touched-line bitmap in LDS, pushed nodes in a compact {r, s} array
+    int lines = 0;                  // the context runs k_arcte_lines (float64 worker / centrality runs)
+    int dense_auto = 0;             // the caller asked for an automatic slot count (dense slots are made on demand)
+    int64_t want_slots = 0, want_queue = 0;   // what the caller asked for at creation
+    DevBuf<uint32_t> edge_rank, node_rank;
+    DevBuf<int64_t> rowspan;
+    DevBuf<double> in_degree_r;
+    int64_t l_slots = 0;
+    uint32_t l_M = 0, l_Mshift = 0, l_qcap = 0, l_pcap = 0, l_scap = 0;
+    int l_waves_per_cu = 0;
+    DevBuf<double> l_vals;
+    DevBuf<double2> l_ps;
+    DevBuf<int32_t> l_sup;
+    DevBuf<QEntry> l_queue;
+    DevBuf<unsigned long long> l_stats;
+    int64_t line_stats[4] = {0, 0, 0, 0};   // last run: LDS updates, blind line writes, read-modify-writes, updates of pushed nodes
     // per-run
     int64_t run_nseeds = -1;
     DevBuf<int32_t> seeds_d, work_pos, out_cnt, status, nop_d;
@@ -254,8 +272,11 @@ struct arcte_hip_ctx {
         return indptr.bytes() + indices.bytes() + data.bytes() + out_degree.bytes() + in_degree.bytes() + edge_in_degree.bytes() + data_f.bytes() + in_degree_f.bytes() + edge_in_degree_f.bytes() + state.bytes() + slot_epoch.bytes() +
                node_hot.bytes() + edge_hot.bytes() + warm.bytes() +
                queue.bytes() + sup.bytes() + seeds_d.bytes() + work_pos.bytes() + out_cnt.bytes() + status.bytes() +
-               nop_d.bytes() + eps_d.bytes() + out_off.bytes() + dst_off.bytes() + raw.bytes() + rows_final.bytes();
+               nop_d.bytes() + eps_d.bytes() + out_off.bytes() + dst_off.bytes() + raw.bytes() + rows_final.bytes() +
+               edge_rank.bytes() + node_rank.bytes() + rowspan.bytes() + in_degree_r.bytes() + slot_bytes_lines();
     }
+    size_t slot_bytes_lines() const { return l_vals.bytes() + l_ps.bytes() + l_sup.bytes() + l_queue.bytes(); }
+    size_t slot_bytes_dense() const { return state.bytes() + sup.bytes() + queue.bytes() + hqueue.bytes() + warm.bytes(); }
 };
 
 namespace {
@@ -340,6 +361,129 @@ uint32_t hot_values_per_wave(const arcte_hip_ctx *c, size_t value_bytes)
     k = std::min<uint64_t>(k, (uint64_t)c->hot_ranked);
     if (cap > 0) k = std::min<uint64_t>(k, (uint64_t)cap);
     return (uint32_t)(k - k % 4);
+}
+
+// ---- line state (arcte_lines.hpp) -----------------------------------------------------------------------------
+// bytes of this device parked in the process-wide buffer cache: hipMemGetInfo does not count them as free, but the
+// next allocation of this process takes them back (or frees them)
+size_t cached_bytes_on(int device)
+{
+    std::lock_guard<std::mutex> lock(g_big_mutex);
+    size_t b = 0;
+    for (const auto &e : g_big_cache)
+        if (e.device == device) b += e.bytes;
+    return b;
+}
+
+// LDS one wavefront of k_arcte_lines may claim: the CU's share, at most what one workgroup may have
+size_t lines_lds_per_wave(const arcte_hip_ctx *c)
+{
+    const size_t reserve = (size_t)std::max(0, env_int("ARCTE_HIP_LDS_RESERVE_KB", 8)) * 1024;
+    const size_t shares = (size_t)std::max(1, c->l_waves_per_cu);
+    size_t per_wave = (LDS_PER_CU - std::min(reserve, LDS_PER_CU / 2)) / shares;
+    per_wave = per_wave / 1024 * 1024;
+    return std::min<size_t>(per_wave, (size_t)64 * 1024);
+}
+
+// values of the LDS level: what the touched-line bitmap (M bits) leaves of the wavefront's share
+uint32_t lines_hot_values(const arcte_hip_ctx *c)
+{
+    const int cap = env_int("ARCTE_HIP_HOT", -1);
+    if (cap == 0) return 0;
+    const size_t per_wave = lines_lds_per_wave(c), bitmap = c->l_M / 8;
+    if (per_wave <= bitmap) return 0;
+    uint64_t k = (per_wave - bitmap) / sizeof(double);
+    k = std::min<uint64_t>(k, (uint64_t)c->n);
+    if (cap > 0) k = std::min<uint64_t>(k, (uint64_t)cap);
+    return (uint32_t)k;
+}
+
+size_t lines_bytes_per_slot(const arcte_hip_ctx *c, uint32_t qcap, uint32_t pcap, uint32_t scap)
+{
+    return ((size_t)c->l_M << 3) * sizeof(double) + (size_t)qcap * sizeof(QEntry) + (size_t)pcap * sizeof(double2) + (size_t)scap * sizeof(int32_t);
+}
+
+int alloc_lines(arcte_hip_ctx *c, int64_t slots, uint32_t qcap, uint32_t pcap, uint32_t scap)
+{
+    // (nothing is cleared: a value is only ever read after the bitmap in LDS said its line was written by this seed)
+    HIP_TRY(alloc_cached(c->l_vals, (size_t)slots * ((size_t)c->l_M << 3), c->device));
+    HIP_TRY(alloc_cached(c->l_queue, (size_t)slots * qcap, c->device));
+    HIP_TRY(alloc_cached(c->l_ps, (size_t)slots * pcap, c->device));
+    HIP_TRY(alloc_cached(c->l_sup, (size_t)slots * scap, c->device));
+    if (!c->l_stats.p) HIP_TRY(c->l_stats.alloc(4));
+    c->l_slots = slots;
+    c->l_qcap = qcap;
+    c->l_pcap = pcap;
+    c->l_scap = scap;
+    return 0;
+}
+
+// a seed ran out of ring, pushed-state or candidate entries: four times as many of those (never more than a seed can
+// need), fewer slots if that is what the memory allows
+int grow_lines(arcte_hip_ctx *c, bool queue_over, bool pushed_over, bool sup_over)
+{
+    uint32_t qcap = c->l_qcap, pcap = c->l_pcap, scap = c->l_scap;
+    const uint32_t node_cap = next_pow2((uint64_t)c->n);
+    if (queue_over) {
+        if (qcap >= (1u << 30)) return fail(ARCTE_HIP_ECAPACITY, "FIFO ring cannot grow past 2^30 entries");
+        qcap *= 4;
+    }
+    if (pushed_over) {
+        if (pcap >= node_cap) return fail(ARCTE_HIP_ECAPACITY, "pushed-state array already holds every node");
+        pcap = std::min<uint32_t>(node_cap, pcap * 4);
+    }
+    if (sup_over) {
+        if (scap >= node_cap) return fail(ARCTE_HIP_ECAPACITY, "candidate list already holds every node");
+        scap = std::min<uint32_t>(node_cap, scap * 4);
+    }
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    free_b += c->slot_bytes_lines() + cached_bytes_on(c->device);
+    int64_t slots = c->l_slots;
+    while (slots > 1 && (size_t)slots * lines_bytes_per_slot(c, qcap, pcap, scap) > free_b / 4 * 3) slots = (slots + 1) / 2;
+    release_cached(c->l_vals, c->device); release_cached(c->l_queue, c->device); release_cached(c->l_ps, c->device); release_cached(c->l_sup, c->device);
+    return alloc_lines(c, slots, qcap, pcap, scap);
+}
+
+template <int MODE, int VAR>
+int launch_lines_v(arcte_hip_ctx *c, const PushParams &P, const LineParams &L, int blocks, size_t lds)
+{
+    auto go = [&](auto kernel) -> int {
+        if (lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kernel, dim3(blocks), dim3(WAVE), lds, c->stream, P, L);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    };
+    if (c->narrow) return go(k_arcte_lines<MODE, VAR, true>);
+    return go(k_arcte_lines<MODE, VAR, false>);
+}
+
+// mode 0: arcte_worker's loop (any push flavour); mode 2: arcte_and_centrality's (ARCTE's own push)
+int launch_lines(arcte_hip_ctx *c, PushParams P, int64_t nwork, int variant, int mode)
+{
+    LineParams L;
+    L.edge_rank = c->edge_rank.p;
+    L.node_rank = c->node_rank.p;
+    L.ranked_ids = c->ranked_ids.p;
+    L.rowspan = c->rowspan.p;
+    L.in_degree_r = c->in_degree_r.p;
+    L.vals = c->l_vals.p;
+    L.ps = c->l_ps.p;
+    L.sup = c->l_sup.p;
+    L.M = c->l_M;
+    L.Mshift = c->l_Mshift;
+    L.pcap = c->l_pcap;
+    L.scap = c->l_scap;
+    L.K = lines_hot_values(c);
+    L.lstats = c->l_stats.p;
+    P.queue = c->l_queue.p;
+    P.qcap = c->l_qcap;
+    const size_t lds = (size_t)L.K * sizeof(double) + c->l_M / 8;
+    const int blocks = (int)std::min<int64_t>(c->l_slots, std::max<int64_t>(nwork, 1));
+    if (mode == 2) return launch_lines_v<2, 0>(c, P, L, blocks, lds);
+    if (variant == 1) return launch_lines_v<0, 1>(c, P, L, blocks, lds);
+    if (variant == 2) return launch_lines_v<0, 2>(c, P, L, blocks, lds);
+    return launch_lines_v<0, 0>(c, P, L, blocks, lds);
 }
 
 template <typename K>
@@ -432,7 +576,7 @@ int prepare_precision(arcte_hip_ctx *c)
         hipLaunchKernelGGL(k_to_float, dim3((unsigned)((c->n + tb - 1) / tb)), dim3(tb), 0, c->stream, c->in_degree.p, c->in_degree_f.p, c->n);
         HIP_TRY(hipGetLastError());
     }
-    if (c->state_is_f32 != c->float32) {
+    if (c->state_is_f32 != c->float32 && c->state.p) {
         if (c->warm.p) HIP_TRY(hipMemsetAsync(c->warm.p, 0, c->warm.bytes(), c->stream));
         HIP_TRY(hipMemsetAsync(c->state.p, 0, c->state.bytes(), c->stream));
         HIP_TRY(hipMemsetAsync(c->slot_epoch.p, 0, c->slot_epoch.bytes(), c->stream));
@@ -522,6 +666,77 @@ int rank_nodes(arcte_hip_ctx *c, DevBuf<uint32_t> &count)
     return rk;
 }
 
+// Slots of the dense-state kernel.  Its launch shape: the kernel is bound by the chip's random-access rate into the
+// per-slot HBM state, and the LDS-resident hot table takes 20-40 % of those accesses away -- the more the fewer
+// wavefronts share a CU's LDS, while fewer wavefronts keep fewer accesses in flight (interleaved A/B on the 1M/50M graph,
+// profiles/r02/ab_interleaved_*.txt, ms per 81 434 seeds: 4 per CU 104.8, 5: 95.0, 6: 93.1, 7: 93.2, 8: 92.0, 10: 97.7,
+// 12: 94.9 -- flat from 6 to 8; 6 needs the least memory of those).
+int setup_dense(arcte_hip_ctx *c, int64_t n_slots, int64_t queue_capacity)
+{
+    const int64_t n = c->n;
+    const int wpb = c->waves_per_block;
+    int64_t slots = n_slots;
+    if (slots <= 0) {
+        c->waves_per_cu = std::max(1, std::min(env_int("ARCTE_HIP_WAVES_PER_CU", c->coop ? 8 : 6), 32));
+        slots = (int64_t)c->waves_per_cu * c->cus;
+        if (c->coop) slots = (int64_t)std::max(1, c->waves_per_cu / 2) * c->cus;       // a slot = a seed = two wavefronts
+        // keep the slot scratch within a fixed share of the device (buffers parked in the cache are ours to reuse)
+        size_t free_b = 0, total_b = 0;
+        HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+        free_b += cached_bytes_on(c->device);
+        size_t per_slot = (size_t)n * (sizeof(Entry) + sizeof(int32_t)) + (size_t)default_queue_capacity(n) * sizeof(QEntry) * (c->coop ? 2 : 1) + (size_t)c->warm_k2 * 16;
+        while (slots > c->cus && (size_t)slots * per_slot > free_b / 4 * 3) slots -= c->cus / 2;
+    }
+    slots = std::max<int64_t>(wpb, (slots + wpb - 1) / wpb * wpb);
+    c->waves_per_cu = (int)std::max<int64_t>(1, std::min<int64_t>(32, (slots + c->cus - 1) / c->cus)) * (c->coop ? 2 : 1);
+    uint32_t qcap = queue_capacity > 0 ? next_pow2((uint64_t)queue_capacity) : default_queue_capacity(n);
+    if (qcap < (uint32_t)WAVE) qcap = WAVE;
+    return alloc_slots(c, slots, qcap);
+}
+
+// The dense state is made when something asks for it: a similarity slice (one slot is enough), a float32 run, a
+// context created with ARCTE_HIP_STATE=dense / ARCTE_HIP_COOP (the caller's slot count).
+int ensure_dense(arcte_hip_ctx *c, bool full)
+{
+    if (c->slots > 0 && (!full || c->dense_auto)) return 0;
+    if (c->slots > 0) {
+        release_cached(c->state, c->device); release_cached(c->sup, c->device); release_cached(c->queue, c->device);
+    }
+    int r = full ? setup_dense(c, c->want_slots, c->want_queue) : setup_dense(c, c->waves_per_block, c->want_queue);
+    if (r) return r;
+    c->dense_auto = full ? 1 : 0;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// Slots of the line-state kernel: M lines of eight float64 per slot, a ring, the pushed-state array, the candidate list.
+int setup_lines(arcte_hip_ctx *c, uint32_t M)
+{
+    const int64_t n = c->n;
+    c->l_M = M;
+    c->l_Mshift = 0;
+    while ((1u << c->l_Mshift) < M) c->l_Mshift++;
+    uint32_t qcap = c->want_queue > 0 ? next_pow2((uint64_t)c->want_queue) : default_queue_capacity(n);
+    if (qcap < (uint32_t)WAVE) qcap = WAVE;
+    const uint32_t node_cap = next_pow2((uint64_t)n);
+    // a seed of the 1M/50M graph pushes 190 distinct nodes (p99 600, tools/line_study.py) and lists a few thousand
+    // candidates; what does not fit is re-run with four times the room (grow_lines)
+    const uint32_t pcap = std::min<uint32_t>(node_cap, (uint32_t)std::max(64, env_int("ARCTE_HIP_PUSHED", 1024)));
+    const uint32_t scap = std::min<uint32_t>(node_cap, (uint32_t)std::max(64, env_int("ARCTE_HIP_CANDIDATES", 65536)));
+    int64_t slots = c->want_slots;
+    if (slots <= 0) {
+        c->l_waves_per_cu = std::max(1, std::min(env_int("ARCTE_HIP_WAVES_PER_CU", 6), 32));
+        slots = (int64_t)c->l_waves_per_cu * c->cus;
+        size_t free_b = 0, total_b = 0;
+        HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+        free_b += cached_bytes_on(c->device);
+        while (slots > c->cus && (size_t)slots * lines_bytes_per_slot(c, qcap, pcap, scap) > free_b / 4 * 3) slots -= c->cus / 2;
+    }
+    slots = std::max<int64_t>(1, slots);
+    c->l_waves_per_cu = (int)std::max<int64_t>(1, std::min<int64_t>(32, (slots + c->cus - 1) / c->cus));
+    return alloc_lines(c, slots, qcap, pcap, scap);
+}
+
 // Everything after the transition matrix and the degree vectors are on the device (indptr, indices, data,
 // out_degree, in_degree): per-edge in_degree, node ranking, hot-table ranks, launch shape, slots.
 int ctx_finish(arcte_hip_ctx *c, int64_t n_slots, int64_t queue_capacity)
@@ -580,12 +795,21 @@ int ctx_finish(arcte_hip_ctx *c, int64_t n_slots, int64_t queue_capacity)
         HIP_TRY(hipGetLastError());
         c->hot_ranked = ranked;
     }
-    // ---- launch shape.  The propagation kernel is bound by the chip's random-access rate into the per-slot HBM
-    //      state, and the LDS-resident hot table takes 20-40 % of those accesses away -- the more the fewer
-    //      wavefronts share a CU's LDS, while fewer wavefronts keep fewer accesses in flight.
-    // warm table: the ranks behind the LDS table keep their one value in a compact per-slot array (A/B on the 1M/50M
-    // graph: 110.3 -> 105.6 ms per 81 434 seeds at 4 wavefronts per CU, 115.9 -> 105.6 at 8; the same within 1.5 % for an
-    // end rank of 16 384, 32 768 or 65 535, so the middle one: 0.5 MB per slot)
+    // ---- rank space (k_arcte_lines names nodes by rank): rank of every node and of every edge's target, row bounds
+    //      and in_degree by rank
+    {
+        const int tb = 256;
+        HIP_TRY(c->node_rank.alloc(n));
+        HIP_TRY(c->edge_rank.alloc(nnz));
+        HIP_TRY(c->rowspan.alloc(2 * n));
+        HIP_TRY(c->in_degree_r.alloc(n));
+        hipLaunchKernelGGL(k_node_rank, dim3((unsigned)((n + tb - 1) / tb)), dim3(tb), 0, c->stream, c->ranked_ids.p, n, c->node_rank.p);
+        hipLaunchKernelGGL(k_rank_space, dim3((unsigned)((n + tb - 1) / tb)), dim3(tb), 0, c->stream, c->ranked_ids.p, c->indptr.p, c->in_degree.p, n,
+                           c->rowspan.p, c->in_degree_r.p);
+        if (nnz) hipLaunchKernelGGL(k_edge_rank, dim3((unsigned)((nnz + tb - 1) / tb)), dim3(tb), 0, c->stream, c->indices.p, c->node_rank.p, c->edge_rank.p, nnz);
+        HIP_TRY(hipGetLastError());
+    }
+    // ---- knobs of the dense-state kernel (k_arcte_seeds: similarity slices, float32, helpers, ARCTE_HIP_STATE=dense)
     c->warm_k2 = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(env_int("ARCTE_HIP_WARM", 32768), c->hot_ranked));
     if (env_int("ARCTE_HIP_HOT", -1) == 0) c->warm_k2 = 0;
     c->waves_per_block = std::max(1, std::min(env_int("ARCTE_HIP_WAVES_PER_BLOCK", 1), WAVES_PER_BLOCK));
@@ -593,27 +817,16 @@ int ctx_finish(arcte_hip_ctx *c, int64_t n_slots, int64_t queue_capacity)
     c->coop_min = std::max(2 * 128, env_int("ARCTE_HIP_COOP_MIN", 512));
     if (c->coop) c->waves_per_block = 1;
     c->tiles = env_int("ARCTE_HIP_TILES", 2) == 4 ? 4 : 2;
-    const int wpb = c->waves_per_block;
-    int64_t slots = n_slots;
-    if (slots <= 0) {
-        // interleaved A/B on the 1M/50M graph with both tables on (profiles/r02/ab_interleaved_*.txt, ms per 81 434
-        // seeds): 4 per CU 104.8, 5: 95.0, 6: 93.1, 7: 93.2, 8: 92.0, 10: 97.7, 12: 94.9 -- flat from 6 to 8; 6 needs
-        // the least memory of those
-        c->waves_per_cu = std::max(1, std::min(env_int("ARCTE_HIP_WAVES_PER_CU", c->coop ? 8 : 6), 32));
-        slots = (int64_t)c->waves_per_cu * c->cus;
-        if (c->coop) slots = (int64_t)std::max(1, c->waves_per_cu / 2) * c->cus;       // a slot = a seed = two wavefronts
-        // keep the slot scratch within a fixed share of the device
-        size_t free_b = 0, total_b = 0;
-        HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-        size_t per_slot = (size_t)n * (sizeof(Entry) + sizeof(int32_t)) + (size_t)default_queue_capacity(n) * sizeof(QEntry) * (c->coop ? 2 : 1) + (size_t)c->warm_k2 * 16;
-        while (slots > c->cus && (size_t)slots * per_slot > free_b / 4 * 3) slots -= c->cus / 2;
-    }
-    slots = std::max<int64_t>(wpb, (slots + wpb - 1) / wpb * wpb);
-    c->waves_per_cu = (int)std::max<int64_t>(1, std::min<int64_t>(32, (slots + c->cus - 1) / c->cus)) * (c->coop ? 2 : 1);
-    uint32_t qcap = queue_capacity > 0 ? next_pow2((uint64_t)queue_capacity) : default_queue_capacity(n);
-    if (qcap < (uint32_t)WAVE) qcap = WAVE;
-    int r = alloc_slots(c, slots, qcap);
+    c->want_slots = n_slots;
+    c->want_queue = queue_capacity;
+    // ---- which state?  Lines whenever every rank has a place in them: 8 M values per slot, M bits of LDS per wavefront.
+    const char *state_env = getenv("ARCTE_HIP_STATE");
+    const uint32_t lines_max = (uint32_t)std::max(64, env_int("ARCTE_HIP_LINES_MAX", 131072));
+    const uint32_t M = std::max<uint32_t>(64u, next_pow2((uint64_t)((n + 7) / 8)));
+    c->lines = !(state_env && state_env[0] == 'd') && !c->coop && M <= lines_max;
+    int r = c->lines ? setup_lines(c, M) : setup_dense(c, n_slots, queue_capacity);
     if (r) return r;
+    if (!c->lines) c->dense_auto = 1;
     HIP_TRY(hipStreamSynchronize(c->stream));
     return 0;
 }
@@ -698,7 +911,7 @@ int transition_on_device(arcte_hip_ctx *c)
 
 extern "C" {
 
-int arcte_hip_abi_version(void) { return 7; }
+int arcte_hip_abi_version(void) { return 8; }
 
 const char *arcte_hip_last_error(void) { return g_err.c_str(); }
 
@@ -950,6 +1163,9 @@ int arcte_hip_destroy(arcte_hip_ctx *c)
     release_cached(c->contrib_key, c->device); release_cached(c->contrib_val, c->device);
     release_cached(c->contrib_key_sorted, c->device); release_cached(c->contrib_val_sorted, c->device);
     c->contrib_temp.release(); c->run_first.release(); c->run_last.release();
+    release_cached(c->l_vals, c->device); release_cached(c->l_queue, c->device); release_cached(c->l_ps, c->device); release_cached(c->l_sup, c->device);
+    c->l_vals.release(); c->l_queue.release(); c->l_ps.release(); c->l_sup.release(); c->l_stats.release();
+    c->edge_rank.release(); c->node_rank.release(); c->rowspan.release(); c->in_degree_r.release();
     c->state.release(); c->slot_epoch.release(); c->warm.release(); c->contrib_key.release(); c->contrib_val.release(); c->centrality.release(); c->ranked_ids.release(); c->node_hot.release(); c->edge_hot.release(); c->edge_in_degree.release(); c->data_f.release(); c->in_degree_f.release(); c->edge_in_degree_f.release(); c->queue.release(); c->hqueue.release(); c->prof.release(); c->sup.release();
     c->seeds_d.release(); c->work_pos.release(); c->out_cnt.release(); c->status.release(); c->nop_d.release();
     c->eps_d.release(); c->out_off.release(); c->dst_off.release(); c->counters.release();
@@ -1073,10 +1289,16 @@ static int run_seeds_impl(arcte_hip_ctx *c, const int64_t *seeds, int64_t nseeds
     c->run_nseeds = -1;
     c->centrality_run = 0;
     if (mode == 2 && (variant != 0 || c->float32)) return fail(ARCTE_HIP_EINVAL, "the centrality driver runs ARCTE's own push in float64");
+    const bool use_lines = c->lines && !c->float32;      // (float32 is the tolerance sweep of the dense-state kernel)
+    if (!use_lines) {
+        int rd = ensure_dense(c, true);
+        if (rd) return rd;
+    }
     {
         int rp = prepare_precision(c);
         if (rp) return rp;
     }
+    for (auto &x : c->line_stats) x = 0;
     c->final_rows = 0;
     for (auto &s : c->stats) s = 0;
     c->candidates = 0;
@@ -1086,7 +1308,7 @@ static int run_seeds_impl(arcte_hip_ctx *c, const int64_t *seeds, int64_t nseeds
     if (r) return r;
     // epochs are 32-bit and advance by one per seed and slot: clear long before any slot can wrap
     c->seeds_since_clear += (uint64_t)nseeds;
-    if (c->seeds_since_clear > (1ull << 31)) {
+    if (c->seeds_since_clear > (1ull << 31) && c->state.p) {
         if (c->warm.p) HIP_TRY(hipMemsetAsync(c->warm.p, 0, c->warm.bytes(), c->stream));
         HIP_TRY(hipMemsetAsync(c->state.p, 0, c->state.bytes(), c->stream));
         HIP_TRY(hipMemsetAsync(c->slot_epoch.p, 0, c->slot_epoch.bytes(), c->stream));
@@ -1228,12 +1450,15 @@ static int run_seeds_impl(arcte_hip_ctx *c, const int64_t *seeds, int64_t nseeds
         P.contrib_cursor = c->counters.p + 8;
         P.contrib_seed_base = c->contrib_seed_base;
         P.contrib_shift = c->contrib_shift;
+        if (use_lines) HIP_TRY(hipMemsetAsync(c->l_stats.p, 0, c->l_stats.bytes(), c->stream));
         HIP_TRY(hipEventRecord(c->ev[2], c->stream));
-        r = (mode == 2) ? launch_centrality(c, P, nwork) : launch_seeds<0>(c, P, nwork, variant);
+        if (use_lines) r = launch_lines(c, P, nwork, variant, mode);
+        else r = (mode == 2) ? launch_centrality(c, P, nwork) : launch_seeds<0>(c, P, nwork, variant);
         if (r) return r;
         HIP_TRY(hipEventRecord(c->ev[3], c->stream));
         launches++;
-        unsigned long long cnt8[10];
+        unsigned long long cnt8[10], lst[4] = {0, 0, 0, 0};
+        if (use_lines) HIP_TRY(hipMemcpyAsync(lst, c->l_stats.p, sizeof(lst), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipMemcpyAsync(cnt8, c->counters.p, sizeof(cnt8), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipMemcpyAsync(status_h.data(), c->status.p, nseeds * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipMemcpyAsync(cnt_h.data(), c->out_cnt.p, nseeds * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
@@ -1242,12 +1467,13 @@ static int run_seeds_impl(arcte_hip_ctx *c, const int64_t *seeds, int64_t nseeds
         HIP_TRY(hipEventElapsedTime(&ms, c->ev[2], c->ev[3]));
         ms_push += ms;
         for (int i = 0; i < 4; i++) c->stats[i] += (int64_t)cnt8[2 + i];
+        for (int i = 0; i < 4; i++) c->line_stats[i] += (int64_t)lst[i];
         c->candidates += (int64_t)cnt8[7];
         c->split_rows += (int64_t)cnt8[9];
 
         // finished seeds of this launch: their rows are appended to rows_final in caller (position) order
         next.clear();
-        bool queue_over = false, out_over = false, contrib_over = false;
+        bool queue_over = false, out_over = false, contrib_over = false, pushed_over = false, sup_over = false;
         int64_t add = 0;
         std::vector<int32_t> by_pos(work);
         std::sort(by_pos.begin(), by_pos.end());
@@ -1268,12 +1494,17 @@ static int run_seeds_impl(arcte_hip_ctx *c, const int64_t *seeds, int64_t nseeds
                 queue_over |= (st == ST_QUEUE_OVERFLOW);
                 out_over |= (st == ST_OUTPUT_OVERFLOW);
                 contrib_over |= (st == ST_CONTRIB_OVERFLOW);
+                pushed_over |= (st == ST_PUSHED_OVERFLOW);
+                sup_over |= (st == ST_SUP_OVERFLOW);
                 next.push_back(pos);
             }
         }
         if (mode == 2 && !next.empty()) {
             if (contrib_over) return RC_CONTRIB_FULL;
-            if (queue_over) {
+            if (use_lines && (queue_over || pushed_over || sup_over)) {
+                r = grow_lines(c, queue_over, pushed_over, sup_over);
+                if (r) return r;
+            } else if (queue_over) {
                 r = grow_queue(c);
                 if (r) return r;
             }
@@ -1311,7 +1542,10 @@ static int run_seeds_impl(arcte_hip_ctx *c, const int64_t *seeds, int64_t nseeds
         }
         if (!next.empty()) {
             c->stats[4] += (int64_t)next.size();
-            if (queue_over) {
+            if (use_lines && (queue_over || pushed_over || sup_over)) {
+                r = grow_lines(c, queue_over, pushed_over, sup_over);
+                if (r) return r;
+            } else if (queue_over) {
                 r = grow_queue(c);
                 if (r) return r;
             }
@@ -1722,6 +1956,9 @@ static int similarity_slice_impl(arcte_hip_ctx *c, int64_t seed, double rho, dou
     HIP_TRY(hipSetDevice(c->device));
     c->run_nseeds = -1;
     {
+        // works on the caller's dense s and r (any content): the dense-state kernel on slot 0
+        int rd0 = ensure_dense(c, false);
+        if (rd0) return rd0;
         int rp = prepare_precision(c);
         if (rp) return rp;
     }
@@ -2284,6 +2521,15 @@ int arcte_hip_launch_occupancy(arcte_hip_ctx *c, int *workgroups_per_cu)
 {
     if (!c || !workgroups_per_cu) return fail(ARCTE_HIP_EINVAL, "bad argument");
     HIP_TRY(hipSetDevice(c->device));
+    if (c->lines && !c->float32) {
+        const size_t lds = (size_t)lines_hot_values(c) * sizeof(double) + c->l_M / 8;
+        int per_cu = 0;
+        auto kernel = c->narrow ? k_arcte_lines<0, 0, true> : k_arcte_lines<0, 0, false>;
+        if (lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, WAVE, lds));
+        *workgroups_per_cu = per_cu;
+        return 0;
+    }
     const uint32_t k = hot_values_per_wave(c, sizeof(double));
     const size_t lds = (size_t)c->waves_per_block * k * sizeof(double);
     int per_cu = 0;
@@ -2300,6 +2546,19 @@ int arcte_hip_launch_occupancy(arcte_hip_ctx *c, int *workgroups_per_cu)
 int arcte_hip_info(arcte_hip_ctx *c, int64_t info[10])
 {
     if (!c || !info) return fail(ARCTE_HIP_EINVAL, "bad argument");
+    if (c->lines && !c->float32) {
+        info[0] = c->l_slots;
+        info[1] = c->l_qcap;
+        info[2] = (int64_t)c->device_bytes();
+        info[3] = c->cus;
+        info[4] = 1;
+        info[5] = lines_hot_values(c);
+        info[6] = LT;
+        info[7] = c->l_waves_per_cu;
+        info[8] = c->narrow ? 1 : 0;
+        info[9] = 0;
+        return 0;
+    }
     info[0] = c->slots;
     info[1] = c->qcap;
     info[2] = (int64_t)c->device_bytes();
@@ -2310,6 +2569,22 @@ int arcte_hip_info(arcte_hip_ctx *c, int64_t info[10])
     info[7] = c->waves_per_cu;
     info[8] = (c->narrow && !c->float32) ? 1 : 0;
     info[9] = c->warm_k2;
+    return 0;
+}
+
+int arcte_hip_state_info(arcte_hip_ctx *c, int64_t info[12])
+{
+    if (!c || !info) return fail(ARCTE_HIP_EINVAL, "bad argument");
+    const bool lines = c->lines && !c->float32;
+    info[0] = lines ? 1 : 0;
+    info[1] = lines ? (int64_t)c->l_M : 0;
+    info[2] = lines ? (int64_t)c->l_pcap : 0;
+    info[3] = lines ? (int64_t)c->l_scap : 0;
+    info[4] = (int64_t)(lines ? c->slot_bytes_lines() : c->slot_bytes_dense());
+    info[5] = lines ? (int64_t)(c->l_M / 8) : 0;
+    info[6] = lines ? (int64_t)lines_lds_per_wave(c) : 0;
+    info[7] = 0;
+    for (int i = 0; i < 4; i++) info[8 + i] = c->line_stats[i];
     return 0;
 }
 

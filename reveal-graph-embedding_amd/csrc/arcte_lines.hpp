@@ -1,0 +1,542 @@
+// The per-seed propagation + extraction kernel of round 3 ("line state"), gfx950 / wave64.  Included by arcte_hip.hip
+// after arcte_kernels.hpp (shares its helpers, PushParams, QEntry, SeedStatus).
+//
+// Same algorithm, same operation order per location as k_arcte_seeds (similarity.py:149-222, push.py:41-64,
+// arcte.py:352-376) -- what changes is WHERE a seed's state lives, because that is what the kernel is bound by.
+// Measured (tools/line_wall.hip, tools/line_study.py): the chip moves ~40 G random 64-byte requests per second whatever
+// their size or direction; a read-modify-write of a cold entry costs two of them, and 80 % of a seed's cold updates are
+// FIRST touches of their node -- the read fetches a stale line only to learn that the node is untouched.
+//
+//   * Nodes are named by RANK (descending pattern in-count) inside the kernel.  The row streams carry ranks
+//     (edge_rank), the per-node arrays are indexed by rank (rowspan, in_degree_r), results are translated back
+//     (ranked_ids) when they are emitted.
+//   * LDS level: ranks < K keep their one value (r == s until the node is pushed) on chip, as before.
+//   * Line level: every other rank < 8 M has ONE float64 in a per-slot array, laid out STRIDED: value index =
+//     (rank mod M) * 8 + rank div M, so the eight nodes of a 64-byte line are M ranks apart -- one frequently touched
+//     node shares its line with seven rarely touched ones.  A bitmap of M bits in LDS (zeroed per seed: it IS the
+//     reference's s[:] = 0; r[:] = 0, arcte.py:337-338) says which lines the seed has touched.  The first touch of a line
+//     is a BLIND whole-line write (the deposit in its place, zeros in the seven others): no read, one full-line
+//     request.  The arbiter is an LDS atomic OR, so two lanes that meet in an untouched line are ordered without a
+//     memory round trip: one writes the line, the other reads it afterwards.  Only re-touches of a line are
+//     read-modify-writes.  No epoch tags, no 32-byte entries: 8 bytes per node and slot.
+//   * Pushed nodes (and the seed) need r and s apart: they move to a compact per-slot array PS[j] = {r, s}, j = order
+//     of first push, and leave a NaN whose payload is j in their value's place (LDS or line level alike).  A seed
+//     pushes ~190 distinct nodes: 3 KB that stay in the L2.
+//   * The row walk is a FOUR-stage software pipeline (rows i+3, slot values i+2, pushed-state i+1, add/store/enqueue i):
+//     every stage issues its loads unconditionally, so no stage has to drain the ones behind it.
+#pragma once
+
+#include "arcte_kernels.hpp"
+
+namespace {
+
+constexpr int32_t ST_PUSHED_OVERFLOW = 6;   // more distinct pushed nodes than PS holds: re-run with a larger one
+constexpr int32_t ST_SUP_OVERFLOW = 7;      // more candidates than the list holds
+
+struct LineParams {
+    const uint32_t *edge_rank;    // [nnz] rank of every stored edge's target (CSR order = FIFO order is kept)
+    const uint32_t *node_rank;    // [n]
+    const int32_t *ranked_ids;    // [n] rank -> node
+    const int64_t *rowspan;       // [2n] by rank: first and one-past-last edge of the node's row
+    const double *in_degree_r;    // [n] by rank
+    double *vals;                 // [slots][8 M]
+    double2 *ps;                  // [slots][pcap]
+    int32_t *sup;                 // [slots][scap] candidate list (ranks)
+    uint32_t M, Mshift;           // lines per slot (power of two), log2
+    uint32_t pcap, scap;
+    uint32_t K;                   // values of the LDS level
+    unsigned long long *lstats;   // [0] LDS updates [1] blind line writes [2] read-modify-writes [3] updates of pushed nodes
+};
+
+__device__ __forceinline__ double moved_to(uint32_t j) { return __longlong_as_double((long long)(0x7FF8DEAD00000000ull | (uint64_t)j)); }
+__device__ __forceinline__ bool moved_is(double x) { return (uint32_t)((uint64_t)__double_as_longlong(x) >> 32) == 0x7FF8DEADu; }
+__device__ __forceinline__ uint32_t moved_index(double x) { return (uint32_t)(uint64_t)__double_as_longlong(x); }
+
+constexpr int LT = 2;                       // 64-edge tiles per pipeline step
+struct LRow { bool a[LT]; uint32_t v[LT]; double w[LT], d[LT]; };
+struct LSlot { double x[LT]; bool owner[LT]; };
+struct LPushed { double2 q[LT]; };
+
+template <int MODE, int VAR, bool NARROW>
+__global__ __launch_bounds__(WAVE) void k_arcte_lines(PushParams P, LineParams L)
+{
+    static_assert(MODE == 0 || MODE == 2, "worker or centrality");
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const int lane = threadIdx.x;
+    const int64_t slot = blockIdx.x;
+    const GraphDev &g = P.g;
+    const uint32_t K = L.K;
+    const uint32_t Mmask = L.M - 1, Mshift = L.Mshift;
+    double *hot = reinterpret_cast<double *>(lds_raw);
+    uint32_t *bm = reinterpret_cast<uint32_t *>(hot + K);
+    double *__restrict__ vals = L.vals + slot * ((int64_t)L.M << 3);
+    double2 *__restrict__ ps = L.ps + slot * (int64_t)L.pcap;
+    int32_t *__restrict__ sup = L.sup + slot * (int64_t)L.scap;
+    QEntry *__restrict__ q = P.queue + slot * (int64_t)P.qcap;
+    const uint32_t qmask = P.qcap - 1;
+    const double omr = P.one_minus_rho;
+
+    auto next_work = [&]() -> unsigned long long {
+        __builtin_amdgcn_wave_barrier();          // see k_arcte_seeds: keeps the draw out of jump threading's reach
+        unsigned long long w = 0;
+        if (lane == 0) w = atomicAdd(P.work_counter, 1ULL);
+        return bcast_u64(w);
+    };
+    auto value_index = [&](uint32_t rk) -> uint32_t { return ((rk & Mmask) << 3) | (rk >> Mshift); };
+    auto line_touched = [&](uint32_t rk) -> bool { const uint32_t ln = rk & Mmask; return (bm[ln >> 5] >> (ln & 31)) & 1u; };
+    // the value that stands in a node's place: on chip, in its line, or 0 when the line has not been touched
+    auto raw_value = [&](uint32_t rk) -> double {
+        if (rk < K) return hot[rk];
+        return line_touched(rk) ? vals[value_index(rk)] : 0.0;
+    };
+    // a node that HAS a value (it was deposited to): no look at the bitmap
+    auto live_value = [&](uint32_t rk) -> double { return rk < K ? hot[rk] : vals[value_index(rk)]; };
+
+    unsigned long long drawn = 0;
+    unsigned long long c_lds = 0, c_blind = 0, c_rmw = 0, c_moved = 0;
+    for (unsigned long long wk = next_work(); wk < (unsigned long long)P.nwork && drawn <= (unsigned long long)P.nwork;
+         wk = next_work(), drawn++) {
+        const int32_t pos = P.work_pos ? P.work_pos[wk] : (int32_t)wk;
+        const int32_t seed = P.seeds[pos];
+        const uint32_t sr = L.node_rank[seed];
+        const double eps = P.eps[pos];
+        {
+            unsigned long long cur = 0;
+            if (lane == 0) cur = __hip_atomic_load(P.raw_cursor, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            cur = bcast_u64(cur);
+            if (cur > P.rawcap) {          // the arena is full: the host drains it and runs this seed again
+                if (lane == 0) {
+                    P.status[pos] = ST_OUTPUT_OVERFLOW;
+                    P.out_cnt[pos] = 0;
+                    P.out_off[pos] = 0;
+                    P.nop[pos] = 0;
+                    atomicAdd(&P.stats[4], 1ULL);
+                }
+                continue;
+            }
+        }
+        // s[:] = 0; r[:] = 0 (arcte.py:337-338): the on-chip values and the touched-line bitmap
+        for (uint32_t i = lane; i < K; i += WAVE) hot[i] = 0.0;
+        {
+            uint64_t *bm64 = reinterpret_cast<uint64_t *>(bm);
+            for (uint32_t i = lane; i < (L.M >> 6); i += WAVE) bm64[i] = 0;
+        }
+
+        uint32_t head = 0, tail = 0;
+        int32_t nsup = 0, nfirst = 0;
+        double cand_thr = 0.0;
+        int32_t npush = 0;
+        uint32_t npushed = 0;          // entries of PS in use
+        unsigned long long nedges = 0;
+        bool ok = true, runaway = false;
+        int32_t fail_status = ST_QUEUE_OVERFLOW;
+
+        auto load_row = [&](int64_t base, int64_t re, double w_row, LRow &R) {
+#pragma unroll
+            for (int t = 0; t < LT; t++) {
+                const int64_t k = base + t * WAVE + lane;
+                R.a[t] = k < re;
+                const int64_t kk = R.a[t] ? k : re - 1;
+                R.v[t] = L.edge_rank[kk];
+                if (NARROW) { R.w[t] = w_row; R.d[t] = (double)g.edge_in_degree_f[kk]; }
+                else { R.w[t] = g.data[kk]; R.d[t] = g.edge_in_degree[kk]; }
+            }
+        };
+
+        // ---- push.py:60-64 over the edges [rb, re) of u's row + the ordered enqueue of similarity.py:194-196 / :214-216
+        auto walk = [&](uint32_t u, double c, double r_self, bool s_self_known, double s_self, int64_t rb, int64_t re, double w_row,
+                        bool do_enqueue) __attribute__((always_inline)) {
+            // stage 2: claim untouched lines (LDS atomic OR: exactly one lane per line sees the bit clear), write them
+            // blind -- 0 + p == p, so the line is complete at once -- and load the values of the touched ones
+            auto slots = [&](const LRow &R, LSlot &E) {
+#pragma unroll
+                for (int t = 0; t < LT; t++) {
+                    const uint32_t rk = R.v[t];
+                    const bool line_lvl = R.a[t] && rk >= K;
+                    const uint32_t ln = rk & Mmask;
+                    bool owner = false;
+                    if (line_lvl) {
+                        const uint32_t bit = 1u << (ln & 31);
+                        const uint32_t old = atomicOr(&bm[ln >> 5], bit);
+                        owner = !(old & bit);
+                    }
+                    E.owner[t] = owner;
+                    if (owner) {
+                        const double p = c * R.w[t];
+                        const uint32_t sl = rk >> Mshift;
+                        double2 *line = reinterpret_cast<double2 *>(vals + ((size_t)ln << 3));
+#pragma unroll
+                        for (uint32_t ch = 0; ch < 4; ch++)
+                            line[ch] = (ch == (sl >> 1)) ? ((sl & 1) ? make_double2(0.0, p) : make_double2(p, 0.0)) : make_double2(0.0, 0.0);
+                    }
+                    // (every lane issues the load: the others at a cached address of the slot)
+                    E.x[t] = vals[(line_lvl && !owner) ? value_index(rk) : 0u];
+                }
+            };
+            // stage 3: the value in the node's place; a pushed node's NaN points into PS
+            auto pushed = [&](const LRow &R, LSlot &E, LPushed &Q) {
+#pragma unroll
+                for (int t = 0; t < LT; t++) {
+                    const uint32_t rk = R.v[t];
+                    double x = 0.0;
+                    if (R.a[t]) x = (rk < K) ? hot[rk] : (E.owner[t] ? 0.0 : E.x[t]);
+                    E.x[t] = x;
+                    Q.q[t] = ps[moved_is(x) ? moved_index(x) : 0u];
+                }
+            };
+            // stage 4
+            auto process = [&](const LRow &R, const LSlot &E, const LPushed &Q) {
+#pragma unroll
+                for (int t = 0; t < LT; t++) {
+                    const bool act = R.a[t];
+                    const uint32_t rk = R.v[t];
+                    const double dv = R.d[t];
+                    const double x = E.x[t];
+                    const bool mv = act && moved_is(x);
+                    const double p = c * R.w[t];                                   // push.py:62 / :17 / :38
+                    const double r_old = mv ? ((rk != u) ? Q.q[t].x : r_self) : x;   // a self-loop sees r[u] as just set
+                    const double s_old = mv ? ((rk == u && s_self_known) ? s_self : Q.q[t].y) : ((VAR == 0) ? x : 0.0);
+                    const double r_new = r_old + p;                                // push.py:64
+                    const double s_new = (VAR == 0) ? s_old + p : s_old;           // push.py:63 (ARCTE only)
+                    if (act) {
+                        if (mv) ps[moved_index(x)] = make_double2(r_new, s_new);
+                        else if (rk < K) hot[rk] = r_new;
+                        else if (!E.owner[t]) vals[value_index(rk)] = r_new;
+                    }
+                    c_moved += __popcll(__ballot(mv));
+                    c_lds += __popcll(__ballot(act && !mv && rk < K));
+                    c_blind += __popcll(__ballot(act && E.owner[t]));
+                    c_rmw += __popcll(__ballot(act && !mv && rk >= K && !E.owner[t]));
+                    if (VAR == 0) {
+                        // candidate list (see k_arcte_seeds): nodes whose s/in_degree has reached a lower bound of the final threshold
+                        const double bar = cand_thr * dv;
+                        const bool cross = act && (s_new > 0.0 && s_new >= bar) && !(s_old > 0.0 && s_old >= bar);
+                        const uint64_t mc = __ballot(cross);
+                        if (mc) {
+                            if ((uint32_t)nsup + (uint32_t)__popcll(mc) > L.scap) { ok = false; fail_status = ST_SUP_OVERFLOW; }
+                            else {
+                                if (cross) sup[nsup + lane_below(mc)] = (int32_t)rk;
+                                nsup += __popcll(mc);
+                            }
+                        }
+                        nfirst += __popcll(__ballot(act && s_old == 0.0 && s_new != 0.0));
+                    }
+                    if (!do_enqueue) continue;
+                    const bool enq = act && (r_new / dv >= eps);                   // similarity.py:194/214
+                    const uint64_t me = __ballot(enq);
+                    const uint32_t cnt = __popcll(me);
+                    if (cnt) {
+                        if (tail - head + cnt > P.qcap) { ok = false; fail_status = ST_QUEUE_OVERFLOW; }
+                        else {
+                            if (enq) {
+                                QEntry e;
+                                e.v = (int32_t)rk; e.h = 0; e.d = dv;
+                                q[(tail + lane_below(me)) & qmask] = e;
+                            }
+                            tail += cnt;
+                        }
+                    }
+                }
+            };
+            constexpr int64_t STEP = LT * WAVE;
+            if (re - rb > STEP) {
+                LRow R0, R1, R2, R3;
+                LSlot E0, E1, E2;
+                LPushed Q0, Q1;
+                load_row(rb, re, w_row, R0);
+                load_row(rb + STEP, re, w_row, R1);
+                load_row(rb + 2 * STEP, re, w_row, R2);
+                slots(R0, E0);
+                slots(R1, E1);
+                pushed(R0, E0, Q0);
+                for (int64_t base = rb; base < re; base += STEP) {
+                    load_row(base + 3 * STEP, re, w_row, R3);
+                    slots(R2, E2);
+                    pushed(R1, E1, Q1);
+                    process(R0, E0, Q0);
+                    if (!ok) break;
+                    R0 = R1; R1 = R2; R2 = R3; E0 = E1; E1 = E2; Q0 = Q1;
+                }
+            } else if (re > rb) {
+                LRow R0;
+                LSlot E0;
+                LPushed Q0;
+                load_row(rb, re, w_row, R0);
+                slots(R0, E0);
+                pushed(R0, E0, Q0);
+                process(R0, E0, Q0);
+            }
+        };
+
+        // ---- one push of node u (push.py:41-64).  `ru` is r[u] at pop time, `ju` its place in PS (-1: not pushed yet,
+        //      its one value stands for r == s)
+        auto push = [&](uint32_t u, int32_t ju, double ru, int64_t rb, int64_t re, bool do_enqueue) {
+            double c, r_self, s_self = 0.0;
+            bool s_known = false;
+            if (VAR == 0) { c = omr * ru; r_self = 0.0; }                                                  // push.py:56,59
+            else if (VAR == 1) { c = omr * ru; r_self = 0.0; }                                             // push.py:11,15
+            else { c = omr * (1 - P.lazy) * ru; r_self = omr * P.lazy * (ru); }                            // push.py:30-31
+            const double A = P.rho * ru;                                                                   // push.py:10 / :29
+            if (ju < 0) {
+                // first push: the node moves to PS (s[u] == r[u] == ru for ARCTE, s[u] == 0 for the PageRank flavours)
+                if (npushed >= L.pcap) { ok = false; fail_status = ST_PUSHED_OVERFLOW; return; }
+                ju = (int32_t)npushed++;
+                s_self = (VAR == 0) ? ru : 0.0 + A;                                                        // push.py:14 / :34
+                s_known = true;
+                if (lane == 0) {
+                    ps[ju] = make_double2(r_self, s_self);
+                    if (u < K) hot[u] = moved_to((uint32_t)ju);
+                    else vals[value_index(u)] = moved_to((uint32_t)ju);
+                }
+                if (VAR != 0) {
+                    const bool grew = s_self != 0.0;
+                    if (grew) {
+                        if ((uint32_t)nsup >= L.scap) { ok = false; fail_status = ST_SUP_OVERFLOW; return; }
+                        if (lane == 0) sup[nsup] = (int32_t)u;       // s is non-zero exactly at pushed nodes
+                        nsup++; nfirst++;
+                    }
+                }
+            } else if (VAR == 0) {
+                if (lane == 0) reinterpret_cast<double *>(ps + ju)[0] = 0.0;                               // push.py:59
+            } else {
+                const double s_old = ps[ju].y;
+                s_self = s_old + A;                                                                        // push.py:14 / :34
+                s_known = true;
+                if (lane == 0) ps[ju] = make_double2(r_self, s_self);                                      // push.py:15 / :35
+                if (s_old == 0.0 && s_self != 0.0) {
+                    if ((uint32_t)nsup >= L.scap) { ok = false; fail_status = ST_SUP_OVERFLOW; return; }
+                    if (lane == 0) sup[nsup] = (int32_t)u;
+                    nsup++; nfirst++;
+                }
+            }
+            const double w_row = (NARROW && re > rb) ? g.data[rb] : 0.0;
+            walk(u, c, r_self, s_known, s_self, rb, re, w_row, do_enqueue);
+            npush++;
+            nedges += (unsigned long long)(re - rb);
+            if (npush >= P.max_pushes) { ok = false; runaway = true; }
+        };
+
+        // ---- similarity.py:176-192: s[seed] = r[seed] = 1, one unconditional push.  The seed's state is PS[0] from the start.
+        const int64_t seed_b = L.rowspan[2 * (int64_t)sr], seed_e = L.rowspan[2 * (int64_t)sr + 1];
+        const double seed_d = L.in_degree_r[sr];
+        if (lane == 0) {
+            ps[0] = make_double2(1.0, (VAR == 0) ? 1.0 : 0.0);          // similarity.py:176-177 / :26 / :85
+            if (sr < K) hot[sr] = moved_to(0);
+            else {
+                const uint32_t ln = sr & Mmask, sl = sr >> Mshift;
+                bm[ln >> 5] |= 1u << (ln & 31);
+                double2 *line = reinterpret_cast<double2 *>(vals + ((size_t)ln << 3));
+                const double m0 = moved_to(0);
+                for (uint32_t ch = 0; ch < 4; ch++)
+                    line[ch] = (ch == (sl >> 1)) ? ((sl & 1) ? make_double2(0.0, m0) : make_double2(m0, 0.0)) : make_double2(0.0, 0.0);
+            }
+            if (VAR == 0) sup[0] = (int32_t)sr;
+        }
+        npushed = 1;
+        nsup = (VAR == 0) ? 1 : 0;
+        nfirst = (VAR == 0) ? 1 : 0;
+        if (MODE == 0 && VAR == 0) {
+            // lower bound of the selection threshold (arcte.py:358-360), see k_arcte_seeds
+            double lb = 1.0 / seed_d;
+            const double c0 = omr * 1.0;
+            for (int64_t k = seed_b + lane; k < seed_e; k += WAVE) {
+                const double x = (c0 * g.data[k]) / g.edge_in_degree[k];
+                lb = (x < lb) ? x : lb;
+            }
+            cand_thr = wave_min(lb) * cand_margin<double>();
+        }
+        push(sr, 0, 1.0, seed_b, seed_e, true);
+        if (VAR == 2) {
+            // similarity.py:108-116: re-push the seed while it stays above the threshold, no enqueue
+            while (ok) {
+                const double ru2 = ps[0].x;
+                if (!(ru2 / seed_d >= eps)) break;
+                push(sr, 0, ru2, seed_b, seed_e, false);
+            }
+        }
+
+        // ---- similarity.py:199-216: FIFO with duplicates, 64 entries per batch (see k_arcte_seeds)
+        // r of node rk, and where it lives: its place in PS when it has been pushed
+        auto read_r = [&](uint32_t rk, int32_t &j) -> double {
+            const double x = live_value(rk);          // queued nodes were deposited to: they have a value
+            j = -1;
+            if (moved_is(x)) { j = (int32_t)moved_index(x); return ps[j].x; }
+            return x;
+        };
+        while (ok && head != tail) {
+            const uint32_t navail = tail - head;
+            const uint32_t bn = navail < (uint32_t)WAVE ? navail : (uint32_t)WAVE;
+            const bool valid = (uint32_t)lane < bn;
+            uint32_t u_l = 0;
+            int32_t j_l = -1;
+            double r_l = 0.0, d_l = 1.0;
+            int64_t rb_l = 0, re_l = 0;
+            if (valid) {
+                const QEntry e = q[(head + lane) & qmask];
+                u_l = (uint32_t)e.v;
+                d_l = e.d;
+                r_l = read_r(u_l, j_l);
+                const longlong2 sp = *reinterpret_cast<const longlong2 *>(L.rowspan + 2 * (int64_t)u_l);
+                rb_l = sp.x;
+                re_l = sp.y;
+            }
+            head += bn;
+            int consumed = 0;
+            bool pass = valid && (r_l / d_l >= eps);                                  // similarity.py:204
+            for (;;) {
+                const uint64_t m = __ballot(pass && lane >= consumed);
+                if (m == 0) break;
+                const int i = __ffsll((unsigned long long)m) - 1;
+                const uint32_t u = (uint32_t)__shfl((int)u_l, i, WAVE);
+                const double du = shfl_f64(d_l, i);
+                consumed = i + 1;
+                // this entry's pop time is now: read r again (the node may have been pushed in between)
+                int32_t ju = -1;
+                const double ru = read_r(u, ju);
+                if (!(ru / du >= eps)) {
+                    if (lane == i) pass = false;
+                    continue;
+                }
+                const int64_t rb = shfl_i64(rb_l, i);
+                const int64_t re = shfl_i64(re_l, i);
+                push(u, ju, ru, rb, re, true);
+                if (VAR == 2) {
+                    // similarity.py:136-144: re-push the same node while it stays above the threshold
+                    while (ok) {
+                        int32_t j2 = -1;
+                        const double ru2 = read_r(u, j2);
+                        if (!(ru2 / du >= eps)) break;
+                        push(u, j2, ru2, rb, re, false);
+                    }
+                }
+                if (!ok) break;
+                // re-test the entries that did not pass: the push may have lifted them over the threshold
+                if (valid && lane >= consumed && !pass) {
+                    r_l = read_r(u_l, j_l);
+                    pass = r_l / d_l >= eps;
+                }
+            }
+        }
+
+        // ---- arcte.py:352-376: degree-normalise, threshold = min over the closed neighbourhood, select, emit
+        auto s_of = [&](uint32_t rk) -> double {
+            const double x = raw_value(rk);
+            if (moved_is(x)) return ps[moved_index(x)].y;
+            return (VAR == 0) ? x : 0.0;
+        };
+        int32_t sta = ok ? ST_OK : (runaway ? ST_RUNAWAY : fail_status);
+        int32_t emitted = 0, support = 0;
+        const int32_t ncand = nsup;
+        unsigned long long off = 0;
+        if (ok) {
+            const double s_seed = ps[0].y;
+            double thr = s_seed / seed_d;
+            bool miss = s_seed == 0.0, selfloop = false;
+            for (int64_t k = seed_b + lane; k < seed_e; k += WAVE) {
+                const uint32_t rk = L.edge_rank[k];
+                selfloop |= (rk == sr);
+                const double sv = s_of(rk);
+                miss |= (sv == 0.0);
+                const double x = sv / g.edge_in_degree[k];
+                thr = (x < thr) ? x : thr;
+            }
+            thr = wave_min(thr);
+            const bool missing = __ballot(miss) != 0;
+            const bool any_selfloop = __ballot(selfloop) != 0;
+            unsigned long long coff = 0;
+            bool contribute = false;
+            if (MODE == 2) {
+                if (lane == 0) coff = atomicAdd(P.contrib_cursor, (unsigned long long)nsup);
+                coff = bcast_u64(coff);
+                contribute = coff + (unsigned long long)nsup <= P.contrib_cap;
+                if (!contribute) sta = ST_CONTRIB_OVERFLOW;
+            }
+            const int64_t base_size = (MODE == 2) ? (seed_e - seed_b) + (any_selfloop ? 0 : 1) : (seed_e - seed_b) + 1;
+            if (MODE != 2 && VAR == 0 && missing) sta = ST_MISSING_BASE;
+            else if (VAR != 0 && (missing || any_selfloop)) {
+                support = nfirst;                    // arcte.py:129-133
+            } else {
+                int32_t cnt = 0;
+                for (int32_t i0 = 0; i0 < nsup; i0 += WAVE) {
+                    const int32_t i = i0 + lane;
+                    bool sel = false;
+                    int32_t rk = 0;
+                    if (i < nsup) {
+                        rk = sup[i];
+                        const double sv = s_of((uint32_t)rk);
+                        const double dv = L.in_degree_r[rk];
+                        const double xn = sv / dv;
+                        sel = xn >= thr;                                          // arcte.py:363-367
+                        if (MODE == 2) {
+                            sel = sel && !missing;
+                            if (contribute) {
+                                P.contrib_key[coff + i] = ((uint64_t)(uint32_t)L.ranked_ids[rk] << P.contrib_shift) | (uint64_t)(seed - P.contrib_seed_base);
+                                P.contrib_val[coff + i] = xn;
+                            }
+                        }
+                    }
+                    const uint64_t ms = __ballot(sel);
+                    if (sel) sup[cnt + lane_below(ms)] = rk;                  // in place: cnt <= i0
+                    cnt += __popcll(ms);
+                }
+                support = nfirst;
+                if ((int64_t)cnt > base_size && sta == ST_OK) {                   // arcte.py:370 / arcte.pyx:211
+                    if (lane == 0) off = atomicAdd(P.raw_cursor, (unsigned long long)cnt);
+                    off = bcast_u64(off);
+                    if (off + (unsigned long long)cnt > P.rawcap) sta = ST_OUTPUT_OVERFLOW;
+                    else {
+                        for (int32_t i = lane; i < cnt; i += WAVE) P.raw[off + i] = L.ranked_ids[sup[i]];
+                        emitted = cnt;
+                    }
+                }
+            }
+        }
+        if (lane == 0) {
+            P.status[pos] = sta;
+            P.out_cnt[pos] = emitted;
+            P.out_off[pos] = (int64_t)off;
+            P.nop[pos] = npush;
+            if (sta == ST_OK) {
+                atomicAdd(&P.stats[0], (unsigned long long)npush);
+                atomicAdd(&P.stats[1], nedges);
+                atomicAdd(&P.stats[2], (unsigned long long)tail);
+                atomicAdd(&P.stats[3], (unsigned long long)support);
+                atomicAdd(&P.stats[5], (unsigned long long)ncand);
+            } else {
+                atomicAdd(&P.stats[4], 1ULL);
+            }
+        }
+    }
+    if (lane == 0 && L.lstats) {
+        atomicAdd(L.lstats + 0, c_lds);
+        atomicAdd(L.lstats + 1, c_blind);
+        atomicAdd(L.lstats + 2, c_rmw);
+        atomicAdd(L.lstats + 3, c_moved);
+    }
+}
+
+// ---- rank space: the per-node arrays by rank, the rank of every edge's target ---------------------------------
+__global__ void k_node_rank(const int32_t *ranked_ids, int64_t n, uint32_t *node_rank)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) node_rank[ranked_ids[i]] = (uint32_t)i;
+}
+
+__global__ void k_rank_space(const int32_t *ranked_ids, const int64_t *indptr, const double *in_degree, int64_t n, int64_t *rowspan,
+                             double *in_degree_r)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t v = ranked_ids[i];
+    rowspan[2 * i] = indptr[v];
+    rowspan[2 * i + 1] = indptr[v + 1];
+    in_degree_r[i] = in_degree[v];
+}
+
+__global__ void k_edge_rank(const int32_t *indices, const uint32_t *node_rank, uint32_t *edge_rank, int64_t nnz)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < nnz) edge_rank[k] = node_rank[indices[k]];
+}
+
+}  // namespace
