@@ -32,7 +32,9 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
-KERNEL_SOURCES = ("reveal-graph-embedding_amd/csrc/arcte_kernels.hpp", "reveal-graph-embedding_amd/csrc/arcte_hip.hip")
+KERNEL_SOURCES = ("reveal-graph-embedding_amd/csrc/arcte_kernels.hpp", "reveal-graph-embedding_amd/csrc/arcte_lines.hpp",
+                  "reveal-graph-embedding_amd/csrc/arcte_prepare.hpp", "reveal-graph-embedding_amd/csrc/arcte_features.hpp",
+                  "reveal-graph-embedding_amd/csrc/arcte_hip.hip")
 
 
 def kernel_source_id():
@@ -108,9 +110,9 @@ def main():
     ap.add_argument("--rho", type=float, default=0.1)
     ap.add_argument("--epsilon", type=float, default=1e-5)
     ap.add_argument("--slots", type=int, default=0)
-    ap.add_argument("--placement-tries", type=int, default=3,
-                    help="contexts drawn before the run, the fastest on a calibration sample is kept (the kernel's duration "
-                         "belongs to the allocation of the slot buffers: DESIGN.md section 5); 1 = take the first")
+    ap.add_argument("--placement-tries", type=int, default=1,
+                    help="contexts drawn before the run, the fastest on a calibration sample is kept; 1 (default) = take the "
+                         "first, which is what arcte(), arcte_worker() and the console script do")
     ap.add_argument("--gather", choices=["rows", "counts"], default="rows",
                     help="N>1: what rank 0 collects per step (rows = the full result)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (0 = skip)")
@@ -182,6 +184,7 @@ def main():
     seeds = ctx.seed_list()
     shard = shard_seeds(seeds, args.shards, rank)
     info = ctx.info()
+    state = ctx.state_info()
     log("[bench] rank %d: n=%d nnz=%d seeds=%d shard=%d slots=%d device_bytes=%.1f GB" % (
         rank, args.nodes, nnz, seeds.size, shard.size, info["slots"], info["device_bytes"] / 1e9))
 
@@ -235,6 +238,7 @@ def main():
 
     st = ctx.stats()
     tm = ctx.timing()
+    upd = ctx.state_info()
     _, total_rows = ctx.result_sizes()
     if world > 1:
         rows_t = torch.tensor([total_rows], dtype=torch.int64, device=comm_dev)
@@ -314,18 +318,22 @@ def main():
                 "slots_per_gpu": info["slots"], "waves_per_cu": info["waves_per_cu"],
                 "hot_values_per_wave": info["hot_values_per_wave"], "narrow_rows": info["narrow_rows"],
                 "warm_end_rank": info["warm_end_rank"],
+                "state": {k: state[k] for k in ("line_state", "lines_per_slot", "pushed_capacity", "candidate_capacity", "slot_bytes",
+                                                "bitmap_lds_bytes", "lds_bytes_per_wave", "lines_region_b")},
                 "kernel_source_id": kernel_source_id(),
                 "placement_tries": len(placement_ms), "placement_calibration_ms": [round(x, 2) for x in placement_ms],
                 "emitted_rows_rank0": int(total_rows), "emitted_rows_all_ranks": emitted_all, "merged_sha256": merged_sha,
                 "gathered_rows_rank0": int(gathered_rows),
-                "per_seed": {k: st[k] / max(shard.size, 1) for k in ("pushes", "edges", "enqueues", "support")},
+                "per_seed": {k: st[k] / max(shard.size, 1) for k in ("pushes", "edges", "enqueues", "support", "candidates")},
                 "reruns": st["reruns"],
                 "eps_kernel_ms": tm["eps_ms"], "compact_ms": tm["compact_ms"], "call_ms": tm["call_ms"],
                 "result_d2h_ms_rank0": fetch_ms,
                 "pcie_inclusive_seeds_per_s_rank0": shard.size / ((elapsed / max(args.steps, 1)) + fetch_ms * 1e-3),
             },
             "roofline": {
-                "bound": "hbm", "kernel": "k_arcte_seeds<0, %d, %s, %d, %s%s>" % (variant, "float" if args.float32 else "double", info["tiles"],
+                "bound": "hbm",
+                "kernel": ("k_arcte_lines<0, %d, %s>" % (variant, "true" if info["narrow_rows"] else "false")) if state["line_state"] else
+                          "k_arcte_seeds<0, %d, %s, %d, %s%s>" % (variant, "float" if args.float32 else "double", info["tiles"],
                                                                   "true" if info["hot_values_per_wave"] else "false",
                                                                   ", true" if info["narrow_rows"] and info["hot_values_per_wave"] else ""),
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -335,6 +343,9 @@ def main():
                                          "how": "arcte_hip_stream_bandwidth: 16 B/lane sweep over 4 GiB on this box, best of 3"},
                 "algorithmic_bytes_per_launch": alg, "kernel_ms_per_launch": kernel_ms,
                 "kernel_ms_each_launch": [round(x, 3) for x in step_kernel_ms],
+                # how the last launch's state updates were served (counted by the kernel), per traversed edge
+                "updates_per_edge": {k: upd[k] / max(st["edges"], 1) for k in ("lds_updates", "blind_line_writes",
+                                                                              "line_read_modify_writes", "pushed_node_updates")},
             },
         }
         if args.variant != "arcte":

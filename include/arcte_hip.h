@@ -321,7 +321,8 @@ int arcte_hip_info(arcte_hip_ctx *ctx, int64_t info[10]);
  * per node and slot in strided 64-byte lines, touched-line bitmap in LDS, pushed nodes in a compact {r, s} array),
  * 0: dense 32-byte entries with epoch tags; [1] lines per slot (M: a slot holds 8 M values); [2] entries of the
  * pushed-state array per slot; [3] entries of the candidate list per slot; [4] bytes of slot scratch held;
- * [5] bytes of LDS the bitmap takes per wavefront; [6] bytes of LDS a wavefront may claim; [7] reserved;
+ * [5] bytes of LDS the bitmap takes per wavefront; [6] bytes of LDS a wavefront may claim; [7] lines per slot of region B
+ * (the ranks beyond 8 M: touched-bits in a per-slot bitmap in global memory; 0 = every rank is covered by the LDS bitmap);
  * of the last run: [8] updates of on-chip values, [9] blind whole-line writes (first touch of a line),
  * [10] read-modify-writes of a line, [11] updates of pushed nodes. */
 int arcte_hip_state_info(arcte_hip_ctx *ctx, int64_t info[12]);

@@ -365,7 +365,7 @@ class Context:
         i = np.zeros(12, dtype=np.int64)
         _check(lib().arcte_hip_state_info(self._h, i))
         return dict(line_state=int(i[0]), lines_per_slot=int(i[1]), pushed_capacity=int(i[2]), candidate_capacity=int(i[3]),
-                    slot_bytes=int(i[4]), bitmap_lds_bytes=int(i[5]), lds_bytes_per_wave=int(i[6]),
+                    slot_bytes=int(i[4]), bitmap_lds_bytes=int(i[5]), lds_bytes_per_wave=int(i[6]), lines_region_b=int(i[7]),
                     lds_updates=int(i[8]), blind_line_writes=int(i[9]), line_read_modify_writes=int(i[10]),
                     pushed_node_updates=int(i[11]))
 

@@ -225,7 +225,8 @@ struct arcte_hip_ctx {
     DevBuf<int64_t> rowspan;
     DevBuf<double> in_degree_r;
     int64_t l_slots = 0;
-    uint32_t l_M = 0, l_Mshift = 0, l_qcap = 0, l_pcap = 0, l_scap = 0;
+    uint32_t l_M = 0, l_Mshift = 0, l_MB = 0, l_MBshift = 0, l_qcap = 0, l_pcap = 0, l_scap = 0;
+    DevBuf<uint32_t> l_gbm;       // [slots][MB / 32] touched-line bits of region B
     int l_waves_per_cu = 0;
     DevBuf<double> l_vals;
     DevBuf<double2> l_ps;
@@ -275,7 +276,7 @@ struct arcte_hip_ctx {
                nop_d.bytes() + eps_d.bytes() + out_off.bytes() + dst_off.bytes() + raw.bytes() + rows_final.bytes() +
                edge_rank.bytes() + node_rank.bytes() + rowspan.bytes() + in_degree_r.bytes() + slot_bytes_lines();
     }
-    size_t slot_bytes_lines() const { return l_vals.bytes() + l_ps.bytes() + l_sup.bytes() + l_queue.bytes(); }
+    size_t slot_bytes_lines() const { return l_vals.bytes() + l_ps.bytes() + l_sup.bytes() + l_queue.bytes() + l_gbm.bytes(); }
     size_t slot_bytes_dense() const { return state.bytes() + sup.bytes() + queue.bytes() + hqueue.bytes() + warm.bytes(); }
 };
 
@@ -400,13 +401,15 @@ uint32_t lines_hot_values(const arcte_hip_ctx *c)
 
 size_t lines_bytes_per_slot(const arcte_hip_ctx *c, uint32_t qcap, uint32_t pcap, uint32_t scap)
 {
-    return ((size_t)c->l_M << 3) * sizeof(double) + (size_t)qcap * sizeof(QEntry) + (size_t)pcap * sizeof(double2) + (size_t)scap * sizeof(int32_t);
+    return (((size_t)c->l_M + c->l_MB) << 3) * sizeof(double) + c->l_MB / 8 + (size_t)qcap * sizeof(QEntry) + (size_t)pcap * sizeof(double2) +
+           (size_t)scap * sizeof(int32_t);
 }
 
 int alloc_lines(arcte_hip_ctx *c, int64_t slots, uint32_t qcap, uint32_t pcap, uint32_t scap)
 {
     // (nothing is cleared: a value is only ever read after the bitmap in LDS said its line was written by this seed)
-    HIP_TRY(alloc_cached(c->l_vals, (size_t)slots * ((size_t)c->l_M << 3), c->device));
+    HIP_TRY(alloc_cached(c->l_vals, (size_t)slots * (((size_t)c->l_M + c->l_MB) << 3), c->device));
+    HIP_TRY(alloc_cached(c->l_gbm, (size_t)slots * (c->l_MB >> 5), c->device));
     HIP_TRY(alloc_cached(c->l_queue, (size_t)slots * qcap, c->device));
     HIP_TRY(alloc_cached(c->l_ps, (size_t)slots * pcap, c->device));
     HIP_TRY(alloc_cached(c->l_sup, (size_t)slots * scap, c->device));
@@ -442,6 +445,7 @@ int grow_lines(arcte_hip_ctx *c, bool queue_over, bool pushed_over, bool sup_ove
     int64_t slots = c->l_slots;
     while (slots > 1 && (size_t)slots * lines_bytes_per_slot(c, qcap, pcap, scap) > free_b / 4 * 3) slots = (slots + 1) / 2;
     release_cached(c->l_vals, c->device); release_cached(c->l_queue, c->device); release_cached(c->l_ps, c->device); release_cached(c->l_sup, c->device);
+    release_cached(c->l_gbm, c->device);
     return alloc_lines(c, slots, qcap, pcap, scap);
 }
 
@@ -454,8 +458,10 @@ int launch_lines_v(arcte_hip_ctx *c, const PushParams &P, const LineParams &L, i
         HIP_TRY(hipGetLastError());
         return 0;
     };
-    if (c->narrow) return go(k_arcte_lines<MODE, VAR, true>);
-    return go(k_arcte_lines<MODE, VAR, false>);
+    const bool tail = c->l_MB > 0;
+    if (c->narrow && c->tiles == 4 && MODE == 0 && VAR == 0) return tail ? go(k_arcte_lines<0, 0, true, true, false, 4>) : go(k_arcte_lines<0, 0, true, false, false, 4>);
+    if (c->narrow) return tail ? go(k_arcte_lines<MODE, VAR, true, true>) : go(k_arcte_lines<MODE, VAR, true, false>);
+    return tail ? go(k_arcte_lines<MODE, VAR, false, true>) : go(k_arcte_lines<MODE, VAR, false, false>);
 }
 
 // mode 0: arcte_worker's loop (any push flavour); mode 2: arcte_and_centrality's (ARCTE's own push)
@@ -472,6 +478,9 @@ int launch_lines(arcte_hip_ctx *c, PushParams P, int64_t nwork, int variant, int
     L.sup = c->l_sup.p;
     L.M = c->l_M;
     L.Mshift = c->l_Mshift;
+    L.MB = c->l_MB;
+    L.MBshift = c->l_MBshift;
+    L.gbm = c->l_gbm.p;
     L.pcap = c->l_pcap;
     L.scap = c->l_scap;
     L.K = lines_hot_values(c);
@@ -481,6 +490,13 @@ int launch_lines(arcte_hip_ctx *c, PushParams P, int64_t nwork, int variant, int
     const size_t lds = (size_t)L.K * sizeof(double) + c->l_M / 8;
     const int blocks = (int)std::min<int64_t>(c->l_slots, std::max<int64_t>(nwork, 1));
     if (mode == 2) return launch_lines_v<2, 0>(c, P, L, blocks, lds);
+    if (c->prof.p && c->narrow && variant == 0) {
+        auto kernel = c->l_MB > 0 ? k_arcte_lines<0, 0, true, true, true> : k_arcte_lines<0, 0, true, false, true>;
+        if (lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kernel, dim3(blocks), dim3(WAVE), lds, c->stream, P, L);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
     if (variant == 1) return launch_lines_v<0, 1>(c, P, L, blocks, lds);
     if (variant == 2) return launch_lines_v<0, 2>(c, P, L, blocks, lds);
     return launch_lines_v<0, 0>(c, P, L, blocks, lds);
@@ -716,6 +732,13 @@ int setup_lines(arcte_hip_ctx *c, uint32_t M)
     c->l_M = M;
     c->l_Mshift = 0;
     while ((1u << c->l_Mshift) < M) c->l_Mshift++;
+    // region B: the ranks the LDS bitmap does not reach (>= 8 M), their touched-bits in global memory
+    c->l_MB = 0;
+    c->l_MBshift = 0;
+    if ((int64_t)M * 8 < n) {
+        c->l_MB = std::max<uint32_t>(128u, next_pow2((uint64_t)((n - (int64_t)M * 8 + 7) / 8)));
+        while ((1u << c->l_MBshift) < c->l_MB) c->l_MBshift++;
+    }
     uint32_t qcap = c->want_queue > 0 ? next_pow2((uint64_t)c->want_queue) : default_queue_capacity(n);
     if (qcap < (uint32_t)WAVE) qcap = WAVE;
     const uint32_t node_cap = next_pow2((uint64_t)n);
@@ -725,7 +748,7 @@ int setup_lines(arcte_hip_ctx *c, uint32_t M)
     const uint32_t scap = std::min<uint32_t>(node_cap, (uint32_t)std::max(64, env_int("ARCTE_HIP_CANDIDATES", 65536)));
     int64_t slots = c->want_slots;
     if (slots <= 0) {
-        c->l_waves_per_cu = std::max(1, std::min(env_int("ARCTE_HIP_WAVES_PER_CU", 6), 32));
+        c->l_waves_per_cu = std::max(1, std::min(env_int("ARCTE_HIP_WAVES_PER_CU", 8), 32));
         slots = (int64_t)c->l_waves_per_cu * c->cus;
         size_t free_b = 0, total_b = 0;
         HIP_TRY(hipMemGetInfo(&free_b, &total_b));
@@ -819,11 +842,14 @@ int ctx_finish(arcte_hip_ctx *c, int64_t n_slots, int64_t queue_capacity)
     c->tiles = env_int("ARCTE_HIP_TILES", 2) == 4 ? 4 : 2;
     c->want_slots = n_slots;
     c->want_queue = queue_capacity;
-    // ---- which state?  Lines whenever every rank has a place in them: 8 M values per slot, M bits of LDS per wavefront.
+    // ---- which state?  Lines (arcte_lines.hpp) unless the dense state is asked for.  The LDS bitmap covers the
+    //      8 M highest-ranked nodes, M = ARCTE_HIP_LINES_LDS at most: on the 1M/50M graph 99.4 % of the traversed edges
+    //      point at the 524 288 highest-ranked nodes (tools/line_study.py), and 8 KB of LDS are worth more as on-chip
+    //      values than as touched-bits of lines that a seed meets once in a hundred times
     const char *state_env = getenv("ARCTE_HIP_STATE");
-    const uint32_t lines_max = (uint32_t)std::max(64, env_int("ARCTE_HIP_LINES_MAX", 131072));
-    const uint32_t M = std::max<uint32_t>(64u, next_pow2((uint64_t)((n + 7) / 8)));
-    c->lines = !(state_env && state_env[0] == 'd') && !c->coop && M <= lines_max;
+    const uint32_t lines_lds = next_pow2((uint64_t)std::max(64, env_int("ARCTE_HIP_LINES_LDS", 65536)));
+    const uint32_t M = std::min<uint32_t>(lines_lds, std::max<uint32_t>(64u, next_pow2((uint64_t)((n + 7) / 8))));
+    c->lines = !(state_env && state_env[0] == 'd') && !c->coop;
     int r = c->lines ? setup_lines(c, M) : setup_dense(c, n_slots, queue_capacity);
     if (r) return r;
     if (!c->lines) c->dense_auto = 1;
@@ -1164,7 +1190,8 @@ int arcte_hip_destroy(arcte_hip_ctx *c)
     release_cached(c->contrib_key_sorted, c->device); release_cached(c->contrib_val_sorted, c->device);
     c->contrib_temp.release(); c->run_first.release(); c->run_last.release();
     release_cached(c->l_vals, c->device); release_cached(c->l_queue, c->device); release_cached(c->l_ps, c->device); release_cached(c->l_sup, c->device);
-    c->l_vals.release(); c->l_queue.release(); c->l_ps.release(); c->l_sup.release(); c->l_stats.release();
+    release_cached(c->l_gbm, c->device);
+    c->l_vals.release(); c->l_queue.release(); c->l_ps.release(); c->l_sup.release(); c->l_stats.release(); c->l_gbm.release();
     c->edge_rank.release(); c->node_rank.release(); c->rowspan.release(); c->in_degree_r.release();
     c->state.release(); c->slot_epoch.release(); c->warm.release(); c->contrib_key.release(); c->contrib_val.release(); c->centrality.release(); c->ranked_ids.release(); c->node_hot.release(); c->edge_hot.release(); c->edge_in_degree.release(); c->data_f.release(); c->in_degree_f.release(); c->edge_in_degree_f.release(); c->queue.release(); c->hqueue.release(); c->prof.release(); c->sup.release();
     c->seeds_d.release(); c->work_pos.release(); c->out_cnt.release(); c->status.release(); c->nop_d.release();
@@ -1594,7 +1621,7 @@ static int run_seeds_impl(arcte_hip_ctx *c, const int64_t *seeds, int64_t nseeds
         HIP_TRY(hipMemcpy(p, c->prof.p, sizeof(p), hipMemcpyDeviceToHost));
         fprintf(stderr, "[arcte_hip profile] ticks: setup %llu pop_batches %llu short_pushes %llu long_pushes %llu pop_loop_rest %llu extraction %llu draw %llu | "
                         "counts: short_pushes %llu long_pushes %llu pop_batches %llu | push_ms %.3f slots %lld\n",
-                p[0], p[1], p[2], p[3], p[4], p[5], p[9], p[6], p[7], p[8], ms_push, (long long)c->slots);
+                p[0], p[1], p[2], p[3], p[4], p[5], p[9], p[6], p[7], p[8], ms_push, (long long)(use_lines ? c->l_slots : c->slots));
     }
     return 0;
 }
@@ -2524,7 +2551,8 @@ int arcte_hip_launch_occupancy(arcte_hip_ctx *c, int *workgroups_per_cu)
     if (c->lines && !c->float32) {
         const size_t lds = (size_t)lines_hot_values(c) * sizeof(double) + c->l_M / 8;
         int per_cu = 0;
-        auto kernel = c->narrow ? k_arcte_lines<0, 0, true> : k_arcte_lines<0, 0, false>;
+        auto kernel = c->narrow ? (c->l_MB > 0 ? k_arcte_lines<0, 0, true, true> : k_arcte_lines<0, 0, true, false>)
+                                : (c->l_MB > 0 ? k_arcte_lines<0, 0, false, true> : k_arcte_lines<0, 0, false, false>);
         if (lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, WAVE, lds));
         *workgroups_per_cu = per_cu;
@@ -2553,7 +2581,7 @@ int arcte_hip_info(arcte_hip_ctx *c, int64_t info[10])
         info[3] = c->cus;
         info[4] = 1;
         info[5] = lines_hot_values(c);
-        info[6] = LT;
+        info[6] = (c->narrow && c->tiles == 4) ? 4 : 2;
         info[7] = c->l_waves_per_cu;
         info[8] = c->narrow ? 1 : 0;
         info[9] = 0;
@@ -2583,7 +2611,7 @@ int arcte_hip_state_info(arcte_hip_ctx *c, int64_t info[12])
     info[4] = (int64_t)(lines ? c->slot_bytes_lines() : c->slot_bytes_dense());
     info[5] = lines ? (int64_t)(c->l_M / 8) : 0;
     info[6] = lines ? (int64_t)lines_lds_per_wave(c) : 0;
-    info[7] = 0;
+    info[7] = lines ? (int64_t)c->l_MB : 0;
     for (int i = 0; i < 4; i++) info[8 + i] = c->line_stats[i];
     return 0;
 }

@@ -39,10 +39,12 @@ struct LineParams {
     const int32_t *ranked_ids;    // [n] rank -> node
     const int64_t *rowspan;       // [2n] by rank: first and one-past-last edge of the node's row
     const double *in_degree_r;    // [n] by rank
-    double *vals;                 // [slots][8 M]
+    double *vals;                 // [slots][8 (M + MB)]
     double2 *ps;                  // [slots][pcap]
     int32_t *sup;                 // [slots][scap] candidate list (ranks)
-    uint32_t M, Mshift;           // lines per slot (power of two), log2
+    uint32_t M, Mshift;           // region A: lines per slot whose touched-bits are in LDS (power of two), log2; ranks < 8 M
+    uint32_t MB, MBshift;         // region B (TAIL): lines for the ranks >= 8 M, touched-bits in gbm (0: every rank is in A)
+    uint32_t *gbm;                // [slots][MB / 32]
     uint32_t pcap, scap;
     uint32_t K;                   // values of the LDS level
     unsigned long long *lstats;   // [0] LDS updates [1] blind line writes [2] read-modify-writes [3] updates of pushed nodes
@@ -52,15 +54,50 @@ __device__ __forceinline__ double moved_to(uint32_t j) { return __longlong_as_do
 __device__ __forceinline__ bool moved_is(double x) { return (uint32_t)((uint64_t)__double_as_longlong(x) >> 32) == 0x7FF8DEADu; }
 __device__ __forceinline__ uint32_t moved_index(double x) { return (uint32_t)(uint64_t)__double_as_longlong(x); }
 
-constexpr int LT = 2;                       // 64-edge tiles per pipeline step
-struct LRow { bool a[LT]; uint32_t v[LT]; double w[LT], d[LT]; };
-struct LSlot { double x[LT]; bool owner[LT]; };
-struct LPushed { double2 q[LT]; };
+// lane (quad base + C)'s value in all four lanes of every quad (DPP quad_perm: no LDS crossbar); every lane must be active
+template <int C> __device__ __forceinline__ uint32_t quad_bcast(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, C * 0x55, 0xF, 0xF, true);
+}
 
-template <int MODE, int VAR, bool NARROW>
+// Blind write of whole lines, one store instruction per lane of the quad: in round C the four lanes of a quad write the
+// four 16-byte chunks of the line that the quad's lane C owns (when it owns one), so every store instruction carries
+// whole, contiguous 64-byte lines and the memory pipeline sees ONE full-line request per line -- 41.7 G mixed updates/s
+// against 22.3 when each lane writes its own line with four 16-byte stores (tools/line_wall.hip, shapes 1 / 0).
+template <int C>
+__device__ __forceinline__ void blind_round(double *vals, int lane, uint32_t own, uint32_t index, uint32_t plo, uint32_t phi)
+{
+    const uint32_t o = quad_bcast<C>(own);
+    const uint32_t ix = quad_bcast<C>(index);          // value index of the owner's node: line = ix / 8, place = ix % 8
+    const double p = __hiloint2double((int)quad_bcast<C>(phi), (int)quad_bcast<C>(plo));
+    if (o) {
+        const uint32_t ql = (uint32_t)lane & 3u, s_ = ix & 7u;
+        const bool hit = ql == (s_ >> 1);
+        reinterpret_cast<double2 *>(vals + (size_t)(ix & ~7u))[ql] = make_double2((hit && !(s_ & 1)) ? p : 0.0, (hit && (s_ & 1)) ? p : 0.0);
+    }
+}
+
+// registers of the pipeline stages, LT 64-edge tiles per step (narrow rows: the weight is the row's, the in_degree a float)
+template <int LT, bool NARROW> struct LRowT { bool a[LT]; uint32_t v[LT]; double w[LT], d[LT]; };
+template <int LT> struct LRowT<LT, true> { bool a[LT]; uint32_t v[LT]; float d[LT]; };
+template <int LT> struct LSlotT { double x[LT]; bool owner[LT]; };
+template <int LT> struct LPushedT { double2 q[LT]; };
+template <int LT> struct LClaimT { uint32_t old[LT]; };
+
+// TAIL: the graph has more ranks than the LDS bitmap covers (8 M); the others' lines have their touched-bits in a
+// per-slot bitmap in global memory (L2-resident for graphs of a few million nodes), claimed by a returning atomic OR one
+// pipeline stage before the line is written or read.
+template <int MODE, int VAR, bool NARROW, bool TAIL, bool PROF = false, int LT = 2>
 __global__ __launch_bounds__(WAVE) void k_arcte_lines(PushParams P, LineParams L)
 {
+    typedef LRowT<LT, NARROW> LRow;
+    typedef LSlotT<LT> LSlot;
+    typedef LPushedT<LT> LPushed;
+    typedef LClaimT<LT> LClaim;
     static_assert(MODE == 0 || MODE == 2, "worker or centrality");
+    // PROF (ARCTE_HIP_PROFILE=1): s_memtime ticks per phase, the indices of PushParams::prof
+    unsigned long long prof[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    auto tick = [&]() -> unsigned long long { return PROF ? (unsigned long long)__builtin_amdgcn_s_memtime() : 0ULL; };
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int lane = threadIdx.x;
     const int64_t slot = blockIdx.x;
@@ -69,7 +106,10 @@ __global__ __launch_bounds__(WAVE) void k_arcte_lines(PushParams P, LineParams L
     const uint32_t Mmask = L.M - 1, Mshift = L.Mshift;
     double *hot = reinterpret_cast<double *>(lds_raw);
     uint32_t *bm = reinterpret_cast<uint32_t *>(hot + K);
-    double *__restrict__ vals = L.vals + slot * ((int64_t)L.M << 3);
+    const uint32_t RA = L.M << 3;                    // first rank of region B
+    const uint32_t MBmask = L.MB - 1, MBshift = L.MBshift;
+    double *__restrict__ vals = L.vals + slot * (((int64_t)L.M + (int64_t)L.MB) << 3);
+    uint32_t *__restrict__ gbm = L.gbm + slot * (int64_t)(L.MB >> 5);
     double2 *__restrict__ ps = L.ps + slot * (int64_t)L.pcap;
     int32_t *__restrict__ sup = L.sup + slot * (int64_t)L.scap;
     QEntry *__restrict__ q = P.queue + slot * (int64_t)P.qcap;
@@ -82,8 +122,16 @@ __global__ __launch_bounds__(WAVE) void k_arcte_lines(PushParams P, LineParams L
         if (lane == 0) w = atomicAdd(P.work_counter, 1ULL);
         return bcast_u64(w);
     };
-    auto value_index = [&](uint32_t rk) -> uint32_t { return ((rk & Mmask) << 3) | (rk >> Mshift); };
-    auto line_touched = [&](uint32_t rk) -> bool { const uint32_t ln = rk & Mmask; return (bm[ln >> 5] >> (ln & 31)) & 1u; };
+    auto in_b = [&](uint32_t rk) -> bool { return TAIL && rk >= RA; };
+    auto value_index = [&](uint32_t rk) -> uint32_t {
+        if (in_b(rk)) { const uint32_t rp = rk - RA; return RA + (((rp & MBmask) << 3) | (rp >> MBshift)); }
+        return ((rk & Mmask) << 3) | (rk >> Mshift);
+    };
+    auto line_touched = [&](uint32_t rk) -> bool {
+        if (in_b(rk)) { const uint32_t ln = (rk - RA) & MBmask; return (gbm[ln >> 5] >> (ln & 31)) & 1u; }
+        const uint32_t ln = rk & Mmask;
+        return (bm[ln >> 5] >> (ln & 31)) & 1u;
+    };
     // the value that stands in a node's place: on chip, in its line, or 0 when the line has not been touched
     auto raw_value = [&](uint32_t rk) -> double {
         if (rk < K) return hot[rk];
@@ -94,8 +142,10 @@ __global__ __launch_bounds__(WAVE) void k_arcte_lines(PushParams P, LineParams L
 
     unsigned long long drawn = 0;
     unsigned long long c_lds = 0, c_blind = 0, c_rmw = 0, c_moved = 0;
+    unsigned long long t_mark = tick();
     for (unsigned long long wk = next_work(); wk < (unsigned long long)P.nwork && drawn <= (unsigned long long)P.nwork;
          wk = next_work(), drawn++) {
+        if (PROF) { const unsigned long long t = tick(); prof[9] += t - t_mark; t_mark = t; }
         const int32_t pos = P.work_pos ? P.work_pos[wk] : (int32_t)wk;
         const int32_t seed = P.seeds[pos];
         const uint32_t sr = L.node_rank[seed];
@@ -120,6 +170,10 @@ __global__ __launch_bounds__(WAVE) void k_arcte_lines(PushParams P, LineParams L
         {
             uint64_t *bm64 = reinterpret_cast<uint64_t *>(bm);
             for (uint32_t i = lane; i < (L.M >> 6); i += WAVE) bm64[i] = 0;
+            if (TAIL) {
+                uint4 *g4 = reinterpret_cast<uint4 *>(gbm);
+                for (uint32_t i = lane; i < (L.MB >> 7); i += WAVE) g4[i] = make_uint4(0, 0, 0, 0);
+            }
         }
 
         uint32_t head = 0, tail = 0;
@@ -138,7 +192,7 @@ __global__ __launch_bounds__(WAVE) void k_arcte_lines(PushParams P, LineParams L
                 R.a[t] = k < re;
                 const int64_t kk = R.a[t] ? k : re - 1;
                 R.v[t] = L.edge_rank[kk];
-                if (NARROW) { R.w[t] = w_row; R.d[t] = (double)g.edge_in_degree_f[kk]; }
+                if constexpr (NARROW) R.d[t] = g.edge_in_degree_f[kk];
                 else { R.w[t] = g.data[kk]; R.d[t] = g.edge_in_degree[kk]; }
             }
         };
@@ -148,41 +202,66 @@ __global__ __launch_bounds__(WAVE) void k_arcte_lines(PushParams P, LineParams L
                         bool do_enqueue) __attribute__((always_inline)) {
             // stage 2: claim untouched lines (LDS atomic OR: exactly one lane per line sees the bit clear), write them
             // blind -- 0 + p == p, so the line is complete at once -- and load the values of the touched ones
-            auto slots = [&](const LRow &R, LSlot &E) {
+            // stage 1 (TAIL): region B's lines are claimed in the global bitmap; the answer is looked at one turn later
+            auto claim = [&](const LRow &R, LClaim &C) {
+#pragma unroll
+                for (int t = 0; t < LT; t++) {
+                    C.old[t] = 0;
+                    if (TAIL && R.a[t] && R.v[t] >= RA) {
+                        const uint32_t ln = (R.v[t] - RA) & MBmask;
+                        C.old[t] = atomicOr(&gbm[ln >> 5], 1u << (ln & 31));
+                    }
+                }
+            };
+            auto slots = [&](const LRow &R, LSlot &E, const LClaim &C) {
 #pragma unroll
                 for (int t = 0; t < LT; t++) {
                     const uint32_t rk = R.v[t];
                     const bool line_lvl = R.a[t] && rk >= K;
-                    const uint32_t ln = rk & Mmask;
                     bool owner = false;
-                    if (line_lvl) {
+                    if (TAIL && line_lvl && rk >= RA) {
+                        const uint32_t ln = (rk - RA) & MBmask;
+                        owner = !((C.old[t] >> (ln & 31)) & 1u);
+                    } else if (line_lvl) {
+                        const uint32_t ln = rk & Mmask;
                         const uint32_t bit = 1u << (ln & 31);
                         const uint32_t old = atomicOr(&bm[ln >> 5], bit);
                         owner = !(old & bit);
                     }
                     E.owner[t] = owner;
-                    if (owner) {
-                        const double p = c * R.w[t];
-                        const uint32_t sl = rk >> Mshift;
-                        double2 *line = reinterpret_cast<double2 *>(vals + ((size_t)ln << 3));
-#pragma unroll
-                        for (uint32_t ch = 0; ch < 4; ch++)
-                            line[ch] = (ch == (sl >> 1)) ? ((sl & 1) ? make_double2(0.0, p) : make_double2(p, 0.0)) : make_double2(0.0, 0.0);
+                    const uint32_t index = value_index(rk);
+                    {
+                        double wt;
+                        if constexpr (NARROW) wt = w_row; else wt = R.w[t];
+                        const double p = c * wt;
+                        const uint32_t own = owner ? 1u : 0u;
+                        const uint32_t plo = (uint32_t)__double2loint(p), phi = (uint32_t)__double2hiint(p);
+                        blind_round<0>(vals, lane, own, index, plo, phi);
+                        blind_round<1>(vals, lane, own, index, plo, phi);
+                        blind_round<2>(vals, lane, own, index, plo, phi);
+                        blind_round<3>(vals, lane, own, index, plo, phi);
                     }
                     // (every lane issues the load: the others at a cached address of the slot)
-                    E.x[t] = vals[(line_lvl && !owner) ? value_index(rk) : 0u];
+                    E.x[t] = vals[(line_lvl && !owner) ? index : 0u];
                 }
             };
             // stage 3: the value in the node's place; a pushed node's NaN points into PS
-            auto pushed = [&](const LRow &R, LSlot &E, LPushed &Q) {
+            // (skip_if_none: a row of one step has nothing to overlap the load with, so it is only issued when some
+            //  target has been pushed -- a wave-uniform branch)
+            auto pushed = [&](const LRow &R, LSlot &E, LPushed &Q, bool skip_if_none) {
+                bool any = false;
 #pragma unroll
                 for (int t = 0; t < LT; t++) {
                     const uint32_t rk = R.v[t];
                     double x = 0.0;
                     if (R.a[t]) x = (rk < K) ? hot[rk] : (E.owner[t] ? 0.0 : E.x[t]);
                     E.x[t] = x;
-                    Q.q[t] = ps[moved_is(x) ? moved_index(x) : 0u];
+                    any |= moved_is(x);
+                    Q.q[t] = make_double2(0.0, 0.0);
                 }
+                if (skip_if_none && __ballot(any) == 0) return;
+#pragma unroll
+                for (int t = 0; t < LT; t++) Q.q[t] = ps[moved_is(E.x[t]) ? moved_index(E.x[t]) : 0u];
             };
             // stage 4
             auto process = [&](const LRow &R, const LSlot &E, const LPushed &Q) {
@@ -190,10 +269,12 @@ __global__ __launch_bounds__(WAVE) void k_arcte_lines(PushParams P, LineParams L
                 for (int t = 0; t < LT; t++) {
                     const bool act = R.a[t];
                     const uint32_t rk = R.v[t];
-                    const double dv = R.d[t];
+                    const double dv = (double)R.d[t];
                     const double x = E.x[t];
                     const bool mv = act && moved_is(x);
-                    const double p = c * R.w[t];                                   // push.py:62 / :17 / :38
+                    double wt;
+                    if constexpr (NARROW) wt = w_row; else wt = R.w[t];
+                    const double p = c * wt;                                       // push.py:62 / :17 / :38
                     const double r_old = mv ? ((rk != u) ? Q.q[t].x : r_self) : x;   // a self-loop sees r[u] as just set
                     const double s_old = mv ? ((rk == u && s_self_known) ? s_self : Q.q[t].y) : ((VAR == 0) ? x : 0.0);
                     const double r_new = r_old + p;                                // push.py:64
@@ -240,30 +321,47 @@ __global__ __launch_bounds__(WAVE) void k_arcte_lines(PushParams P, LineParams L
             };
             constexpr int64_t STEP = LT * WAVE;
             if (re - rb > STEP) {
-                LRow R0, R1, R2, R3;
+                LRow R0, R1, R2, R3, R4;
                 LSlot E0, E1, E2;
                 LPushed Q0, Q1;
+                LClaim C0, C1, C2, C3;
                 load_row(rb, re, w_row, R0);
                 load_row(rb + STEP, re, w_row, R1);
                 load_row(rb + 2 * STEP, re, w_row, R2);
-                slots(R0, E0);
-                slots(R1, E1);
-                pushed(R0, E0, Q0);
+                if (TAIL) load_row(rb + 3 * STEP, re, w_row, R3);
+                claim(R0, C0);
+                claim(R1, C1);
+                claim(R2, C2);
+                slots(R0, E0, C0);
+                slots(R1, E1, C1);
+                pushed(R0, E0, Q0, false);
                 for (int64_t base = rb; base < re; base += STEP) {
-                    load_row(base + 3 * STEP, re, w_row, R3);
-                    slots(R2, E2);
-                    pushed(R1, E1, Q1);
+                    // Everything this turn consumes was issued in the previous one: wait for all of it HERE, once, before
+                    // anything new is issued.  (The counter is in order and counts stores too; the compiler cannot count
+                    // stores under a branch, so a wait placed after them would drain this turn's loads as well.)
+                    __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0)
+                    pushed(R1, E1, Q1, false);
                     process(R0, E0, Q0);
+                    slots(R2, E2, C2);
+                    if (TAIL) {
+                        claim(R3, C3);
+                        load_row(base + 4 * STEP, re, w_row, R4);
+                    } else {
+                        load_row(base + 3 * STEP, re, w_row, R3);
+                    }
                     if (!ok) break;
                     R0 = R1; R1 = R2; R2 = R3; E0 = E1; E1 = E2; Q0 = Q1;
+                    if (TAIL) { R3 = R4; C2 = C3; }
                 }
             } else if (re > rb) {
                 LRow R0;
                 LSlot E0;
                 LPushed Q0;
+                LClaim C0;
                 load_row(rb, re, w_row, R0);
-                slots(R0, E0);
-                pushed(R0, E0, Q0);
+                claim(R0, C0);
+                slots(R0, E0, C0);
+                pushed(R0, E0, Q0, true);
                 process(R0, E0, Q0);
             }
         };
@@ -271,6 +369,7 @@ __global__ __launch_bounds__(WAVE) void k_arcte_lines(PushParams P, LineParams L
         // ---- one push of node u (push.py:41-64).  `ru` is r[u] at pop time, `ju` its place in PS (-1: not pushed yet,
         //      its one value stands for r == s)
         auto push = [&](uint32_t u, int32_t ju, double ru, int64_t rb, int64_t re, bool do_enqueue) {
+            const unsigned long long t_push = tick();
             double c, r_self, s_self = 0.0;
             bool s_known = false;
             if (VAR == 0) { c = omr * ru; r_self = 0.0; }                                                  // push.py:56,59
@@ -314,6 +413,15 @@ __global__ __launch_bounds__(WAVE) void k_arcte_lines(PushParams P, LineParams L
             npush++;
             nedges += (unsigned long long)(re - rb);
             if (npush >= P.max_pushes) { ok = false; runaway = true; }
+            if (PROF) {
+                // (the time of a push is taken out of the phase it interrupts: t_mark moves forward by it)
+                __builtin_amdgcn_s_waitcnt(0x0F70);
+                const unsigned long long dt = tick() - t_push;
+                const bool is_long = re - rb > (int64_t)LT * WAVE;
+                prof[is_long ? 3 : 2] += dt;
+                prof[is_long ? 7 : 6] += 1;
+                t_mark += dt;
+            }
         };
 
         // ---- similarity.py:176-192: s[seed] = r[seed] = 1, one unconditional push.  The seed's state is PS[0] from the start.
@@ -323,9 +431,10 @@ __global__ __launch_bounds__(WAVE) void k_arcte_lines(PushParams P, LineParams L
             ps[0] = make_double2(1.0, (VAR == 0) ? 1.0 : 0.0);          // similarity.py:176-177 / :26 / :85
             if (sr < K) hot[sr] = moved_to(0);
             else {
-                const uint32_t ln = sr & Mmask, sl = sr >> Mshift;
-                bm[ln >> 5] |= 1u << (ln & 31);
-                double2 *line = reinterpret_cast<double2 *>(vals + ((size_t)ln << 3));
+                if (in_b(sr)) { const uint32_t ln = (sr - RA) & MBmask; gbm[ln >> 5] |= 1u << (ln & 31); }
+                else { const uint32_t ln = sr & Mmask; bm[ln >> 5] |= 1u << (ln & 31); }
+                const uint32_t ix = value_index(sr), sl = ix & 7u;
+                double2 *line = reinterpret_cast<double2 *>(vals + (size_t)(ix & ~7u));
                 const double m0 = moved_to(0);
                 for (uint32_t ch = 0; ch < 4; ch++)
                     line[ch] = (ch == (sl >> 1)) ? ((sl & 1) ? make_double2(0.0, m0) : make_double2(m0, 0.0)) : make_double2(0.0, 0.0);
@@ -345,6 +454,7 @@ __global__ __launch_bounds__(WAVE) void k_arcte_lines(PushParams P, LineParams L
             }
             cand_thr = wave_min(lb) * cand_margin<double>();
         }
+        if (PROF) { const unsigned long long t = tick(); prof[0] += t - t_mark; t_mark = t; }
         push(sr, 0, 1.0, seed_b, seed_e, true);
         if (VAR == 2) {
             // similarity.py:108-116: re-push the seed while it stays above the threshold, no enqueue
@@ -383,6 +493,13 @@ __global__ __launch_bounds__(WAVE) void k_arcte_lines(PushParams P, LineParams L
             head += bn;
             int consumed = 0;
             bool pass = valid && (r_l / d_l >= eps);                                  // similarity.py:204
+            if (PROF) {
+                const unsigned long long any = __ballot(pass);        // (the ballot makes the wavefront wait for the loads of the batch)
+                asm volatile("" ::"s"(any));
+                const unsigned long long t = tick();
+                prof[1] += t - t_mark; t_mark = t; prof[8] += 1;
+            }
+            bool fresh = valid;            // r_l is r as of the last push (nothing has been pushed since the batch was read)
             for (;;) {
                 const uint64_t m = __ballot(pass && lane >= consumed);
                 if (m == 0) break;
@@ -390,9 +507,11 @@ __global__ __launch_bounds__(WAVE) void k_arcte_lines(PushParams P, LineParams L
                 const uint32_t u = (uint32_t)__shfl((int)u_l, i, WAVE);
                 const double du = shfl_f64(d_l, i);
                 consumed = i + 1;
-                // this entry's pop time is now: read r again (the node may have been pushed in between)
-                int32_t ju = -1;
-                const double ru = read_r(u, ju);
+                // this entry's pop time is now (similarity.py:204): its r must be the current one -- the node may have been
+                // pushed since it was read (the queue holds duplicates)
+                int32_t ju = __shfl(j_l, i, WAVE);
+                double ru = shfl_f64(r_l, i);
+                if (!__shfl((int)fresh, i, WAVE)) ru = read_r(u, ju);
                 if (!(ru / du >= eps)) {
                     if (lane == i) pass = false;
                     continue;
@@ -410,14 +529,21 @@ __global__ __launch_bounds__(WAVE) void k_arcte_lines(PushParams P, LineParams L
                     }
                 }
                 if (!ok) break;
-                // re-test the entries that did not pass: the push may have lifted them over the threshold
-                if (valid && lane >= consumed && !pass) {
+                // One round trip after the push reads again (a) every waiting entry that did not pass -- the push may have
+                // lifted it over the threshold -- and (b) the passing entry whose turn comes next, so that its pop needs no
+                // second look; the other passing entries are read when their turn comes.
+                fresh = false;
+                const uint64_t mp = __ballot(pass && lane >= consumed);
+                const int nxt = mp ? __ffsll((unsigned long long)mp) - 1 : WAVE;
+                if (valid && lane >= consumed && (!pass || lane == nxt)) {
                     r_l = read_r(u_l, j_l);
                     pass = r_l / d_l >= eps;
+                    fresh = true;
                 }
             }
         }
 
+        if (PROF) { const unsigned long long t = tick(); prof[4] += t - t_mark; t_mark = t; }
         // ---- arcte.py:352-376: degree-normalise, threshold = min over the closed neighbourhood, select, emit
         auto s_of = [&](uint32_t rk) -> double {
             const double x = raw_value(rk);
@@ -506,6 +632,11 @@ __global__ __launch_bounds__(WAVE) void k_arcte_lines(PushParams P, LineParams L
                 atomicAdd(&P.stats[4], 1ULL);
             }
         }
+        if (PROF) { const unsigned long long t = tick(); prof[5] += t - t_mark; t_mark = t; }
+    }
+    if (PROF && lane == 0 && P.prof) {
+#pragma unroll
+        for (int k = 0; k < 10; k++) atomicAdd(P.prof + k, prof[k]);
     }
     if (lane == 0 && L.lstats) {
         atomicAdd(L.lstats + 0, c_lds);

@@ -19,9 +19,9 @@ __device__ __forceinline__ uint64_t mix(uint64_t x)
     return x;
 }
 
-template <int STREAM>
+template <int STREAM, int SHAPE>
 __global__ __launch_bounds__(64) void k(double *tab, uint64_t values_per_wave, uint32_t blind_cut, const double *stream,
-                                        uint64_t stream_elems, int iters, double *sink)
+                                        uint64_t stream_elems, int iters, double *sink, int noload)
 {
     const uint64_t wave = blockIdx.x;
     const int lane = threadIdx.x;
@@ -38,15 +38,33 @@ __global__ __launch_bounds__(64) void k(double *tab, uint64_t values_per_wave, u
         double *at = base + j;
         // this iteration's accesses: blind lanes write their whole line now, the others load their value
         double loaded = 0;
-        if (blind) {
-            double2 *line = reinterpret_cast<double2 *>(base + (j & ~7ull));
-            const int chunk = (int)((j & 7) >> 1);
-            const double p = (double)it;
+        if (SHAPE == 0) {
+            if (blind) {
+                double2 *line = reinterpret_cast<double2 *>(base + (j & ~7ull));
+                const int chunk = (int)((j & 7) >> 1);
+                const double p = (double)it;
 #pragma unroll
-            for (int c = 0; c < 4; c++) line[c] = (c == chunk) ? ((j & 1) ? make_double2(0.0, p) : make_double2(p, 0.0)) : make_double2(0.0, 0.0);
+                for (int c = 0; c < 4; c++) line[c] = (c == chunk) ? ((j & 1) ? make_double2(0.0, p) : make_double2(p, 0.0)) : make_double2(0.0, 0.0);
+            }
+        } else {
+            // quad-cooperative: in instruction c the four lanes of a quad write the four 16-byte chunks of the line of the
+            // quad's c-th lane (when that lane is blind): every store instruction carries whole 64-byte lines
+            const int ql = lane & 3;
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const int src = (lane & ~3) | c;
+                const unsigned long long jj = __shfl((unsigned long long)j, src, 64);
+                const int bl = __shfl((int)blind, src, 64);
+                if (bl) {
+                    double2 *line = reinterpret_cast<double2 *>(base + (jj & ~7ull));
+                    const int chunk = (int)((jj & 7) >> 1);
+                    const double p = (double)it;
+                    line[ql] = (ql == chunk) ? ((jj & 1) ? make_double2(0.0, p) : make_double2(p, 0.0)) : make_double2(0.0, 0.0);
+                }
+            }
         }
-        // (every lane issues the load: a blind lane at a cached dummy address)
-        loaded = *(blind ? stream + lane : at);
+        // (every lane issues the load: a blind lane at a cached dummy address); NOLOAD: pure writes, nothing waits
+        if (!noload) loaded = *(blind ? stream + lane : at);
         if (STREAM) {
 #pragma unroll
             for (int q = 0; q < STREAM / 8; q++) {
@@ -66,11 +84,13 @@ __global__ __launch_bounds__(64) void k(double *tab, uint64_t values_per_wave, u
 
 int main(int argc, char **argv)
 {
-    if (argc < 5) { fprintf(stderr, "usage: line_wall BLIND_PCT SLICE_MB WAVES_PER_CU STREAM_BYTES [ITERS]\n"); return 2; }
+    if (argc < 5) { fprintf(stderr, "usage: line_wall BLIND_PCT SLICE_MB WAVES_PER_CU STREAM_BYTES [ITERS [SHAPE [NOLOAD]]]\n"); return 2; }
     const int blind_pct = atoi(argv[1]);
     const double slice_mb = atof(argv[2]);
     const int wpc = atoi(argv[3]), stream_b = atoi(argv[4]);
     const int iters = argc > 5 ? atoi(argv[5]) : 512;
+    const int shape = argc > 6 ? atoi(argv[6]) : 0;
+    const int noload = argc > 7 ? atoi(argv[7]) : 0;
     const int waves = 256 * wpc;
     const uint64_t vpw = (uint64_t)(slice_mb * 1048576.0 / 8.0) & ~7ull;
     const size_t bytes = (size_t)waves * vpw * 8;
@@ -89,9 +109,13 @@ int main(int argc, char **argv)
     const uint32_t cut = (uint32_t)(65536.0 * blind_pct / 100.0);
     for (int rep = 0; rep < 3; rep++) {
         hipEventRecord(a);
-        if (stream_b == 0) hipLaunchKernelGGL((k<0>), dim3(waves), dim3(64), 0, 0, tab, vpw, cut, st, stream_elems, iters, sink);
-        else if (stream_b == 8) hipLaunchKernelGGL((k<8>), dim3(waves), dim3(64), 0, 0, tab, vpw, cut, st, stream_elems, iters, sink);
-        else hipLaunchKernelGGL((k<16>), dim3(waves), dim3(64), 0, 0, tab, vpw, cut, st, stream_elems, iters, sink);
+        if (shape == 0) {
+            if (stream_b == 0) hipLaunchKernelGGL((k<0, 0>), dim3(waves), dim3(64), 0, 0, tab, vpw, cut, st, stream_elems, iters, sink, noload);
+            else hipLaunchKernelGGL((k<8, 0>), dim3(waves), dim3(64), 0, 0, tab, vpw, cut, st, stream_elems, iters, sink, noload);
+        } else {
+            if (stream_b == 0) hipLaunchKernelGGL((k<0, 1>), dim3(waves), dim3(64), 0, 0, tab, vpw, cut, st, stream_elems, iters, sink, noload);
+            else hipLaunchKernelGGL((k<8, 1>), dim3(waves), dim3(64), 0, 0, tab, vpw, cut, st, stream_elems, iters, sink, noload);
+        }
         hipEventRecord(b);
         hipEventSynchronize(b);
         float ms;
@@ -99,7 +123,7 @@ int main(int argc, char **argv)
         if (rep > 0 && ms < best) best = ms;
     }
     const double ops = (double)waves * 64 * iters;
-    printf("blind %3d%%  slice %6.2f MB (%6.1f GB in all)  %2d waves/CU  stream %2d B/update : %7.2f G updates/s  (%.2f ms)\n", blind_pct,
+    printf("shape %d noload %d  blind %3d%%  slice %6.2f MB (%6.1f GB in all)  %2d waves/CU  stream %2d B/update : %7.2f G updates/s  (%.2f ms)\n", blind_pct,
            slice_mb, bytes / 1073741824.0, wpc, stream_b, ops / best / 1e6, best);
     return 0;
 }
