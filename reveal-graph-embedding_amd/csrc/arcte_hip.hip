@@ -459,9 +459,14 @@ int launch_lines_v(arcte_hip_ctx *c, const PushParams &P, const LineParams &L, i
         return 0;
     };
     const bool tail = c->l_MB > 0;
+    // One 64-edge tile per pipeline step is the default: 149 VGPRs, so three wavefronts per SIMD instead of two (186 with
+    // two tiles), and the kernel wants wavefronts in flight more than it wants long steps (1M/50M graph, ms per 81 434
+    // seeds: two tiles at 8 per CU 91.1; one tile at 9 / 10 / 11 / 12 per CU 89.5 / 81.4 / 78.3 / 76.4).
+    // ARCTE_HIP_TILES=2 / 4 keep the longer steps for ARCTE's worker on narrow rows (A/B).
     if (c->narrow && c->tiles == 4 && MODE == 0 && VAR == 0) return tail ? go(k_arcte_lines<0, 0, true, true, false, 4>) : go(k_arcte_lines<0, 0, true, false, false, 4>);
-    if (c->narrow) return tail ? go(k_arcte_lines<MODE, VAR, true, true>) : go(k_arcte_lines<MODE, VAR, true, false>);
-    return tail ? go(k_arcte_lines<MODE, VAR, false, true>) : go(k_arcte_lines<MODE, VAR, false, false>);
+    if (c->narrow && c->tiles == 2 && MODE == 0 && VAR == 0) return tail ? go(k_arcte_lines<0, 0, true, true, false, 2>) : go(k_arcte_lines<0, 0, true, false, false, 2>);
+    if (c->narrow) return tail ? go(k_arcte_lines<MODE, VAR, true, true, false, 1>) : go(k_arcte_lines<MODE, VAR, true, false, false, 1>);
+    return tail ? go(k_arcte_lines<MODE, VAR, false, true, false, 1>) : go(k_arcte_lines<MODE, VAR, false, false, false, 1>);
 }
 
 // mode 0: arcte_worker's loop (any push flavour); mode 2: arcte_and_centrality's (ARCTE's own push)
@@ -491,7 +496,7 @@ int launch_lines(arcte_hip_ctx *c, PushParams P, int64_t nwork, int variant, int
     const int blocks = (int)std::min<int64_t>(c->l_slots, std::max<int64_t>(nwork, 1));
     if (mode == 2) return launch_lines_v<2, 0>(c, P, L, blocks, lds);
     if (c->prof.p && c->narrow && variant == 0) {
-        auto kernel = c->l_MB > 0 ? k_arcte_lines<0, 0, true, true, true> : k_arcte_lines<0, 0, true, false, true>;
+        auto kernel = c->l_MB > 0 ? k_arcte_lines<0, 0, true, true, true, 1> : k_arcte_lines<0, 0, true, false, true, 1>;
         if (lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kernel, dim3(blocks), dim3(WAVE), lds, c->stream, P, L);
         HIP_TRY(hipGetLastError());
@@ -739,7 +744,8 @@ int setup_lines(arcte_hip_ctx *c, uint32_t M)
         c->l_MB = std::max<uint32_t>(128u, next_pow2((uint64_t)((n - (int64_t)M * 8 + 7) / 8)));
         while ((1u << c->l_MBshift) < c->l_MB) c->l_MBshift++;
     }
-    uint32_t qcap = c->want_queue > 0 ? next_pow2((uint64_t)c->want_queue) : default_queue_capacity(n);
+    // (a seed of the 1M/50M graph enqueues 210 nodes; the ring grows by four and the seed is re-run when it overflows)
+    uint32_t qcap = c->want_queue > 0 ? next_pow2((uint64_t)c->want_queue) : std::min<uint32_t>(default_queue_capacity(n), 1u << 16);
     if (qcap < (uint32_t)WAVE) qcap = WAVE;
     const uint32_t node_cap = next_pow2((uint64_t)n);
     // a seed of the 1M/50M graph pushes 190 distinct nodes (p99 600, tools/line_study.py) and lists a few thousand
@@ -748,12 +754,12 @@ int setup_lines(arcte_hip_ctx *c, uint32_t M)
     const uint32_t scap = std::min<uint32_t>(node_cap, (uint32_t)std::max(64, env_int("ARCTE_HIP_CANDIDATES", 65536)));
     int64_t slots = c->want_slots;
     if (slots <= 0) {
-        c->l_waves_per_cu = std::max(1, std::min(env_int("ARCTE_HIP_WAVES_PER_CU", 8), 32));
+        c->l_waves_per_cu = std::max(1, std::min(env_int("ARCTE_HIP_WAVES_PER_CU", 12), 32));
         slots = (int64_t)c->l_waves_per_cu * c->cus;
         size_t free_b = 0, total_b = 0;
         HIP_TRY(hipMemGetInfo(&free_b, &total_b));
         free_b += cached_bytes_on(c->device);
-        while (slots > c->cus && (size_t)slots * lines_bytes_per_slot(c, qcap, pcap, scap) > free_b / 4 * 3) slots -= c->cus / 2;
+        while (slots > c->cus && (size_t)slots * lines_bytes_per_slot(c, qcap, pcap, scap) > free_b / 20 * 17) slots -= c->cus / 2;
     }
     slots = std::max<int64_t>(1, slots);
     c->l_waves_per_cu = (int)std::max<int64_t>(1, std::min<int64_t>(32, (slots + c->cus - 1) / c->cus));
@@ -839,7 +845,8 @@ int ctx_finish(arcte_hip_ctx *c, int64_t n_slots, int64_t queue_capacity)
     c->coop = env_int("ARCTE_HIP_COOP", 0) != 0 && env_int("ARCTE_HIP_HOT", -1) != 0;
     c->coop_min = std::max(2 * 128, env_int("ARCTE_HIP_COOP_MIN", 512));
     if (c->coop) c->waves_per_block = 1;
-    c->tiles = env_int("ARCTE_HIP_TILES", 2) == 4 ? 4 : 2;
+    c->tiles = env_int("ARCTE_HIP_TILES", 1);
+    if (c->tiles != 2 && c->tiles != 4) c->tiles = 1;
     c->want_slots = n_slots;
     c->want_queue = queue_capacity;
     // ---- which state?  Lines (arcte_lines.hpp) unless the dense state is asked for.  The LDS bitmap covers the
@@ -847,7 +854,7 @@ int ctx_finish(arcte_hip_ctx *c, int64_t n_slots, int64_t queue_capacity)
     //      point at the 524 288 highest-ranked nodes (tools/line_study.py), and 8 KB of LDS are worth more as on-chip
     //      values than as touched-bits of lines that a seed meets once in a hundred times
     const char *state_env = getenv("ARCTE_HIP_STATE");
-    const uint32_t lines_lds = next_pow2((uint64_t)std::max(64, env_int("ARCTE_HIP_LINES_LDS", 65536)));
+    const uint32_t lines_lds = next_pow2((uint64_t)std::max(64, env_int("ARCTE_HIP_LINES_LDS", 32768)));
     const uint32_t M = std::min<uint32_t>(lines_lds, std::max<uint32_t>(64u, next_pow2((uint64_t)((n + 7) / 8))));
     c->lines = !(state_env && state_env[0] == 'd') && !c->coop;
     int r = c->lines ? setup_lines(c, M) : setup_dense(c, n_slots, queue_capacity);
@@ -2551,8 +2558,8 @@ int arcte_hip_launch_occupancy(arcte_hip_ctx *c, int *workgroups_per_cu)
     if (c->lines && !c->float32) {
         const size_t lds = (size_t)lines_hot_values(c) * sizeof(double) + c->l_M / 8;
         int per_cu = 0;
-        auto kernel = c->narrow ? (c->l_MB > 0 ? k_arcte_lines<0, 0, true, true> : k_arcte_lines<0, 0, true, false>)
-                                : (c->l_MB > 0 ? k_arcte_lines<0, 0, false, true> : k_arcte_lines<0, 0, false, false>);
+        auto kernel = c->narrow ? (c->l_MB > 0 ? k_arcte_lines<0, 0, true, true, false, 1> : k_arcte_lines<0, 0, true, false, false, 1>)
+                                : (c->l_MB > 0 ? k_arcte_lines<0, 0, false, true, false, 1> : k_arcte_lines<0, 0, false, false, false, 1>);
         if (lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, WAVE, lds));
         *workgroups_per_cu = per_cu;
@@ -2581,7 +2588,7 @@ int arcte_hip_info(arcte_hip_ctx *c, int64_t info[10])
         info[3] = c->cus;
         info[4] = 1;
         info[5] = lines_hot_values(c);
-        info[6] = (c->narrow && c->tiles == 4) ? 4 : 2;
+        info[6] = (c->narrow && (c->tiles == 4 || c->tiles == 2)) ? c->tiles : 1;
         info[7] = c->l_waves_per_cu;
         info[8] = c->narrow ? 1 : 0;
         info[9] = 0;

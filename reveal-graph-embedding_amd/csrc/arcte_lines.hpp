@@ -87,7 +87,7 @@ template <int LT> struct LClaimT { uint32_t old[LT]; };
 // TAIL: the graph has more ranks than the LDS bitmap covers (8 M); the others' lines have their touched-bits in a
 // per-slot bitmap in global memory (L2-resident for graphs of a few million nodes), claimed by a returning atomic OR one
 // pipeline stage before the line is written or read.
-template <int MODE, int VAR, bool NARROW, bool TAIL, bool PROF = false, int LT = 2>
+template <int MODE, int VAR, bool NARROW, bool TAIL, bool PROF = false, int LT = 1>
 __global__ __launch_bounds__(WAVE) void k_arcte_lines(PushParams P, LineParams L)
 {
     typedef LRowT<LT, NARROW> LRow;
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(WAVE) void k_arcte_lines(PushParams P, LineParams L
 
         // ---- push.py:60-64 over the edges [rb, re) of u's row + the ordered enqueue of similarity.py:194-196 / :214-216
         auto walk = [&](uint32_t u, double c, double r_self, bool s_self_known, double s_self, int64_t rb, int64_t re, double w_row,
-                        bool do_enqueue) __attribute__((always_inline)) {
+                        bool do_enqueue, bool use_pre, const LRow &pre) __attribute__((always_inline)) {
             // stage 2: claim untouched lines (LDS atomic OR: exactly one lane per line sees the bit clear), write them
             // blind -- 0 + p == p, so the line is complete at once -- and load the values of the touched ones
             // stage 1 (TAIL): region B's lines are claimed in the global bitmap; the answer is looked at one turn later
@@ -213,7 +213,9 @@ __global__ __launch_bounds__(WAVE) void k_arcte_lines(PushParams P, LineParams L
                     }
                 }
             };
-            auto slots = [&](const LRow &R, LSlot &E, const LClaim &C) {
+            auto slots = [&](const LRow &R, LSlot &E, const LClaim &C, bool skip_if_none) {
+                uint32_t ld_index[LT];
+                bool any_load = false;
 #pragma unroll
                 for (int t = 0; t < LT; t++) {
                     const uint32_t rk = R.v[t];
@@ -242,8 +244,15 @@ __global__ __launch_bounds__(WAVE) void k_arcte_lines(PushParams P, LineParams L
                         blind_round<3>(vals, lane, own, index, plo, phi);
                     }
                     // (every lane issues the load: the others at a cached address of the slot)
-                    E.x[t] = vals[(line_lvl && !owner) ? index : 0u];
+                    ld_index[t] = (line_lvl && !owner) ? index : 0u;
+                    any_load |= line_lvl && !owner;
+                    E.x[t] = 0.0;
                 }
+                // (skip_if_none: a row of one step waits for these loads at once; when no lane has a value to read --
+                //  first touches and on-chip nodes only -- there is nothing to wait for: a wave-uniform branch)
+                if (skip_if_none && __ballot(any_load) == 0) return;
+#pragma unroll
+                for (int t = 0; t < LT; t++) E.x[t] = vals[ld_index[t]];
             };
             // stage 3: the value in the node's place; a pushed node's NaN points into PS
             // (skip_if_none: a row of one step has nothing to overlap the load with, so it is only issued when some
@@ -332,8 +341,8 @@ __global__ __launch_bounds__(WAVE) void k_arcte_lines(PushParams P, LineParams L
                 claim(R0, C0);
                 claim(R1, C1);
                 claim(R2, C2);
-                slots(R0, E0, C0);
-                slots(R1, E1, C1);
+                slots(R0, E0, C0, false);
+                slots(R1, E1, C1, false);
                 pushed(R0, E0, Q0, false);
                 for (int64_t base = rb; base < re; base += STEP) {
                     // Everything this turn consumes was issued in the previous one: wait for all of it HERE, once, before
@@ -342,7 +351,7 @@ __global__ __launch_bounds__(WAVE) void k_arcte_lines(PushParams P, LineParams L
                     __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0)
                     pushed(R1, E1, Q1, false);
                     process(R0, E0, Q0);
-                    slots(R2, E2, C2);
+                    slots(R2, E2, C2, false);
                     if (TAIL) {
                         claim(R3, C3);
                         load_row(base + 4 * STEP, re, w_row, R4);
@@ -358,9 +367,10 @@ __global__ __launch_bounds__(WAVE) void k_arcte_lines(PushParams P, LineParams L
                 LSlot E0;
                 LPushed Q0;
                 LClaim C0;
-                load_row(rb, re, w_row, R0);
+                if (use_pre) R0 = pre;               // fetched ahead, during the round trip of the previous push's re-test
+                else load_row(rb, re, w_row, R0);
                 claim(R0, C0);
-                slots(R0, E0, C0);
+                slots(R0, E0, C0, true);
                 pushed(R0, E0, Q0, true);
                 process(R0, E0, Q0);
             }
@@ -368,7 +378,7 @@ __global__ __launch_bounds__(WAVE) void k_arcte_lines(PushParams P, LineParams L
 
         // ---- one push of node u (push.py:41-64).  `ru` is r[u] at pop time, `ju` its place in PS (-1: not pushed yet,
         //      its one value stands for r == s)
-        auto push = [&](uint32_t u, int32_t ju, double ru, int64_t rb, int64_t re, bool do_enqueue) {
+        auto push = [&](uint32_t u, int32_t ju, double ru, int64_t rb, int64_t re, bool do_enqueue, bool use_pre, const LRow &pre, double pre_w) {
             const unsigned long long t_push = tick();
             double c, r_self, s_self = 0.0;
             bool s_known = false;
@@ -408,8 +418,8 @@ __global__ __launch_bounds__(WAVE) void k_arcte_lines(PushParams P, LineParams L
                     nsup++; nfirst++;
                 }
             }
-            const double w_row = (NARROW && re > rb) ? g.data[rb] : 0.0;
-            walk(u, c, r_self, s_known, s_self, rb, re, w_row, do_enqueue);
+            const double w_row = use_pre ? pre_w : ((NARROW && re > rb) ? g.data[rb] : 0.0);
+            walk(u, c, r_self, s_known, s_self, rb, re, w_row, do_enqueue, use_pre, pre);
             npush++;
             nedges += (unsigned long long)(re - rb);
             if (npush >= P.max_pushes) { ok = false; runaway = true; }
@@ -455,13 +465,13 @@ __global__ __launch_bounds__(WAVE) void k_arcte_lines(PushParams P, LineParams L
             cand_thr = wave_min(lb) * cand_margin<double>();
         }
         if (PROF) { const unsigned long long t = tick(); prof[0] += t - t_mark; t_mark = t; }
-        push(sr, 0, 1.0, seed_b, seed_e, true);
+        { LRow none; push(sr, 0, 1.0, seed_b, seed_e, true, false, none, 0.0); }
         if (VAR == 2) {
             // similarity.py:108-116: re-push the seed while it stays above the threshold, no enqueue
             while (ok) {
                 const double ru2 = ps[0].x;
                 if (!(ru2 / seed_d >= eps)) break;
-                push(sr, 0, ru2, seed_b, seed_e, false);
+                { LRow none; push(sr, 0, ru2, seed_b, seed_e, false, false, none, 0.0); }
             }
         }
 
@@ -500,6 +510,9 @@ __global__ __launch_bounds__(WAVE) void k_arcte_lines(PushParams P, LineParams L
                 prof[1] += t - t_mark; t_mark = t; prof[8] += 1;
             }
             bool fresh = valid;            // r_l is r as of the last push (nothing has been pushed since the batch was read)
+            LRow PF;                       // the row of entry pf_lane, fetched ahead (rows of one step only)
+            double pf_w = 0.0;
+            int pf_lane = -1;
             for (;;) {
                 const uint64_t m = __ballot(pass && lane >= consumed);
                 if (m == 0) break;
@@ -518,23 +531,34 @@ __global__ __launch_bounds__(WAVE) void k_arcte_lines(PushParams P, LineParams L
                 }
                 const int64_t rb = shfl_i64(rb_l, i);
                 const int64_t re = shfl_i64(re_l, i);
-                push(u, ju, ru, rb, re, true);
+                push(u, ju, ru, rb, re, true, pf_lane == i, PF, pf_w);
                 if (VAR == 2) {
                     // similarity.py:136-144: re-push the same node while it stays above the threshold
                     while (ok) {
                         int32_t j2 = -1;
                         const double ru2 = read_r(u, j2);
                         if (!(ru2 / du >= eps)) break;
-                        push(u, j2, ru2, rb, re, false);
+                        push(u, j2, ru2, rb, re, false, false, PF, 0.0);
                     }
                 }
                 if (!ok) break;
                 // One round trip after the push reads again (a) every waiting entry that did not pass -- the push may have
                 // lifted it over the threshold -- and (b) the passing entry whose turn comes next, so that its pop needs no
-                // second look; the other passing entries are read when their turn comes.
+                // second look (the other passing entries are read when their turn comes), and (c) fetches that entry's row
+                // ahead when it fits one step: the graph does not change, so the row is right whether or not the entry is
+                // pushed in the end.
                 fresh = false;
                 const uint64_t mp = __ballot(pass && lane >= consumed);
                 const int nxt = mp ? __ffsll((unsigned long long)mp) - 1 : WAVE;
+                pf_lane = -1;
+                if (nxt < WAVE) {
+                    const int64_t nb = shfl_i64(rb_l, nxt), ne = shfl_i64(re_l, nxt);
+                    if (ne > nb && ne - nb <= (int64_t)LT * WAVE) {
+                        pf_w = NARROW ? g.data[nb] : 0.0;
+                        load_row(nb, ne, pf_w, PF);
+                        pf_lane = nxt;
+                    }
+                }
                 if (valid && lane >= consumed && (!pass || lane == nxt)) {
                     r_l = read_r(u_l, j_l);
                     pass = r_l / d_l >= eps;
