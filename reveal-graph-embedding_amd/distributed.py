@@ -177,6 +177,10 @@ def arcte_and_centrality_distributed(adjacency_matrix, rho, epsilon, device=None
     cent_t = torch.from_numpy(np.ascontiguousarray(partial, dtype=np.float64)).to(where)
     dist.all_reduce(cent_t, op=dist.ReduceOp.SUM, group=group)           # the one collective of this driver
     centrality = cent_t.cpu().numpy()
+    # arcte.pyx:210 ASSIGNS 1.0 to the nodes that were no seeds (no out-edges).  A rank does that inside its own node
+    # block only, while the other ranks' seeds have ADDED s/in_degree to the same node: the rule is applied again to the
+    # sum, on every rank, so that a sink with in-edges ends at 1.0 exactly as in the one-context run.
+    centrality[np.diff(a.indptr) == 0] = 1.0
     counts_t = torch.from_numpy(np.diff(colptr).astype(np.int64)).to(where)
     rows_t = torch.from_numpy(np.ascontiguousarray(rows, dtype=np.int32)).to(where)
     gathered = gather_shards(counts_t, rows_t, dst=0, group=group)

@@ -141,6 +141,53 @@ def test_sharded_arcte_and_centrality(tmp_path, world, name):
     np.testing.assert_allclose(cs[0], g["centrality"], rtol=1e-13, atol=0)
 
 
+def _sink_graph():
+    """ba300 with the out-edges of nodes 5 and 17 removed: two sinks that keep their in-edges."""
+    import scipy.sparse as sparse
+    from test_centrality_weighting_cpu import load_centrality
+    a = sparse.lil_matrix(load_centrality("ba300")["adjacency"])
+    a[5, :] = 0
+    a[17, :] = 0
+    a = sparse.csr_matrix(a)
+    a.eliminate_zeros()
+    return a
+
+
+def _sink_worker(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import oracle
+    from reveal_graph_embedding_amd.distributed import arcte_and_centrality_distributed
+
+    def run_block(adjacency, lo, hi, rho, eps):
+        return oracle.centrality_block(adjacency, rho, eps, lo, hi)
+    run_block.transition = lambda a: oracle.get_natural_random_walk_matrix(a)[0]
+    run_block.normalize = oracle.normalize_community_features
+    _, c = arcte_and_centrality_distributed(_sink_graph(), 0.1, 1e-4, run_block=run_block)
+    np.save(out_path + ".c%d.npy" % rank, c)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_centrality_of_sinks_with_in_edges(tmp_path):
+    """arcte.pyx:210 assigns 1.0 to the nodes without out-edges; a rank does so in its own block only while the other
+    ranks add to the same node, so the rule has to be applied to the all-reduced sum (round-2 advisor finding)."""
+    from oracle import oracle
+    a = _sink_graph()
+    assert a.indptr[6] == a.indptr[5] and a[:, 5].nnz > 0
+    out = str(tmp_path / "c")
+    mp.spawn(_sink_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    _, _, whole = oracle.centrality_block(a, 0.1, 1e-4, 0, a.shape[0])
+    assert whole[5] == 1.0 and whole[17] == 1.0
+    for r in range(2):
+        c = np.load(out + ".c%d.npy" % r)
+        assert c[5] == 1.0 and c[17] == 1.0
+        np.testing.assert_allclose(c, whole, rtol=1e-13, atol=0)
+
+
 def _hip_centrality_worker(rank, world, port, name, out_path):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
