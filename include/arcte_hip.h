@@ -297,6 +297,15 @@ int arcte_hip_peak_snr_weights(int device, int64_t n_classes, int64_t n_cols, co
  * zeros are eliminated, rows are l2-normalised. */
 int arcte_hip_features_community_weighting(arcte_hip_features *f, const double *community_weights);
 
+/* The reference's parent process SUMS its workers' n x n matrices (embedding/arcte/arcte.py:670-673); every seed owns
+ * its column, so the sum is a concatenation.  This entry appends another worker's result -- its seeds, their community
+ * sizes and the members (int32 node ids, concatenated; `rows` may point to host memory or to memory of any GPU of this
+ * process: hipMemcpyDefault) -- to the completed run of `ctx`, after which arcte_hip_result_csr_size /
+ * arcte_hip_fetch_result_csr / arcte_hip_features_from_result assemble the matrix of ALL parts on ctx's GPU, as they do
+ * for a one-GPU run.  A seed must not appear in two parts. */
+int arcte_hip_append_result(arcte_hip_ctx *ctx, const int64_t *seeds, const int64_t *counts, int64_t nseeds, const void *rows,
+                            int64_t nrows);
+
 /*
  * Measurement helper (no counterpart in the reference; SURVEY.md 8(d) asks for the on-box streaming rate beside
  * the 8 TB/s spec figure): the rate of a coalesced 16-byte-per-lane read sweep and of a copy (read + write bytes)

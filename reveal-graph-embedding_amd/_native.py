@@ -57,6 +57,7 @@ SIGNATURES = {
     "arcte_hip_push": (C.c_int, [C.c_int, C.c_int64, _f64p, _f64p, _f64p, _i32p, C.c_int64, C.c_int64, C.c_double]),
     "arcte_hip_set_float32": (C.c_int, [C.c_void_p, C.c_int]),
     "arcte_hip_stream_bandwidth": (C.c_int, [C.c_int, C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "arcte_hip_append_result": (C.c_int, [C.c_void_p, _i64p, _i64p, C.c_int64, C.c_void_p, C.c_int64]),
     "arcte_hip_info": (C.c_int, [C.c_void_p, _i64p]),
     "arcte_hip_state_info": (C.c_int, [C.c_void_p, _i64p]),
     "arcte_hip_launch_occupancy": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
@@ -359,6 +360,18 @@ class Context:
         return dict(slots=int(i[0]), queue_capacity=int(i[1]), device_bytes=int(i[2]), compute_units=int(i[3]),
                     waves_per_workgroup=int(i[4]), hot_values_per_wave=int(i[5]), tiles=int(i[6]),
                     waves_per_cu=int(i[7]), narrow_rows=int(i[8]), warm_end_rank=int(i[9]))
+
+    def append_result(self, seeds, counts, rows, nrows=None):
+        """Append another worker's part to this context's completed run (arcte_hip_append_result): `rows` is an int32
+        numpy array, or a raw pointer (host or any GPU of this process) together with `nrows`."""
+        seeds = np.ascontiguousarray(seeds, dtype=np.int64)
+        counts = np.ascontiguousarray(counts, dtype=np.int64)
+        if isinstance(rows, np.ndarray):
+            rows = np.ascontiguousarray(rows, dtype=np.int32)
+            ptr, nrows = rows.ctypes.data, rows.size
+        else:
+            ptr = int(rows)
+        _check(lib().arcte_hip_append_result(self._h, seeds, counts, int(seeds.size), C.c_void_p(ptr), int(nrows)))
 
     def state_info(self):
         """Where the per-seed state lives and, of the last run, how its updates were served (arcte_hip_state_info)."""

@@ -465,6 +465,8 @@ int launch_lines_v(arcte_hip_ctx *c, const PushParams &P, const LineParams &L, i
     // ARCTE_HIP_TILES=2 / 4 keep the longer steps for ARCTE's worker on narrow rows (A/B).
     if (c->narrow && c->tiles == 4 && MODE == 0 && VAR == 0) return tail ? go(k_arcte_lines<0, 0, true, true, false, 4>) : go(k_arcte_lines<0, 0, true, false, false, 4>);
     if (c->narrow && c->tiles == 2 && MODE == 0 && VAR == 0) return tail ? go(k_arcte_lines<0, 0, true, true, false, 2>) : go(k_arcte_lines<0, 0, true, false, false, 2>);
+    if (c->narrow && MODE == 0 && VAR == 0 && c->l_waves_per_cu > 12)      // four wavefronts per SIMD: the compiler spills to fit 128 VGPRs
+        return tail ? go(k_arcte_lines<0, 0, true, true, false, 1, 4>) : go(k_arcte_lines<0, 0, true, false, false, 1, 4>);
     if (c->narrow) return tail ? go(k_arcte_lines<MODE, VAR, true, true, false, 1>) : go(k_arcte_lines<MODE, VAR, true, false, false, 1>);
     return tail ? go(k_arcte_lines<MODE, VAR, false, true, false, 1>) : go(k_arcte_lines<MODE, VAR, false, false, false, 1>);
 }
@@ -1953,6 +1955,52 @@ int arcte_hip_copy_result_rows_to_device(arcte_hip_ctx *c, void *dst_dev, int64_
         HIP_TRY(hipMemcpyAsync(dst_dev, c->rows_final.p, c->final_rows * sizeof(int32_t), hipMemcpyDeviceToDevice, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
     }
+    return 0;
+}
+
+int arcte_hip_append_result(arcte_hip_ctx *c, const int64_t *seeds, const int64_t *counts, int64_t nseeds, const void *rows, int64_t nrows)
+{
+    if (!c || nseeds < 0 || nrows < 0 || (nseeds && (!seeds || !counts)) || (nrows && !rows)) return fail(ARCTE_HIP_EINVAL, "bad argument");
+    if (c->run_nseeds < 0) return fail(ARCTE_HIP_ESTATE, "no completed run on this context to append to");
+    if (c->centrality_run) return fail(ARCTE_HIP_ESTATE, "the columns of a centrality run are numbered by a running counter: parts cannot be appended");
+    HIP_TRY(hipSetDevice(c->device));
+    int64_t sum = 0;
+    std::vector<int32_t> s32((size_t)std::max<int64_t>(nseeds, 1));
+    for (int64_t k = 0; k < nseeds; k++) {
+        if (seeds[k] < 0 || seeds[k] >= c->n) return fail(ARCTE_HIP_EINVAL, "seed id out of range");
+        if (counts[k] < 0) return fail(ARCTE_HIP_EINVAL, "negative community size");
+        s32[(size_t)k] = (int32_t)seeds[k];
+        sum += counts[k];
+    }
+    if (sum != nrows) return fail(ARCTE_HIP_EINVAL, "the community sizes do not add up to the number of rows");
+    const int64_t ns0 = c->run_nseeds, rows0 = c->final_rows;
+    if (ns0 + nseeds >= ((int64_t)1 << 31)) return fail(ARCTE_HIP_EINVAL, "too many seeds for one result");
+    // grow the two device arrays, keeping what they hold
+    if ((size_t)(ns0 + nseeds) > c->seeds_d.capacity) {
+        DevBuf<int32_t> bigger;
+        HIP_TRY(bigger.alloc(std::max<size_t>((size_t)(ns0 + nseeds), c->seeds_d.capacity * 2)));
+        if (ns0) HIP_TRY(hipMemcpy(bigger.p, c->seeds_d.p, ns0 * sizeof(int32_t), hipMemcpyDeviceToDevice));
+        c->seeds_d.release();
+        c->seeds_d = bigger;
+        bigger.p = nullptr;
+    }
+    c->seeds_d.count = (size_t)(ns0 + nseeds);
+    if ((size_t)(rows0 + nrows) > c->rows_final.capacity) {
+        DevBuf<int32_t> bigger;
+        HIP_TRY(bigger.alloc(std::max<size_t>((size_t)(rows0 + nrows), c->rows_final.capacity * 2)));
+        if (rows0) HIP_TRY(hipMemcpy(bigger.p, c->rows_final.p, rows0 * sizeof(int32_t), hipMemcpyDeviceToDevice));
+        c->rows_final.release();
+        c->rows_final = bigger;
+        bigger.p = nullptr;
+    }
+    c->rows_final.count = (size_t)(rows0 + nrows);
+    if (nseeds) HIP_TRY(hipMemcpy(c->seeds_d.p + ns0, s32.data(), nseeds * sizeof(int32_t), hipMemcpyHostToDevice));
+    // (hipMemcpyDefault: the rows may lie in host memory or on any device of this process)
+    if (nrows) HIP_TRY(hipMemcpy(c->rows_final.p + rows0, rows, nrows * sizeof(int32_t), hipMemcpyDefault));
+    c->colptr.resize((size_t)(ns0 + nseeds) + 1);
+    for (int64_t k = 0; k < nseeds; k++) c->colptr[(size_t)(ns0 + k) + 1] = c->colptr[(size_t)(ns0 + k)] + counts[k];
+    c->run_nseeds = ns0 + nseeds;
+    c->final_rows = rows0 + nrows;
     return 0;
 }
 

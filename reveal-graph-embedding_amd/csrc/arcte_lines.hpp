@@ -87,8 +87,8 @@ template <int LT> struct LClaimT { uint32_t old[LT]; };
 // TAIL: the graph has more ranks than the LDS bitmap covers (8 M); the others' lines have their touched-bits in a
 // per-slot bitmap in global memory (L2-resident for graphs of a few million nodes), claimed by a returning atomic OR one
 // pipeline stage before the line is written or read.
-template <int MODE, int VAR, bool NARROW, bool TAIL, bool PROF = false, int LT = 1>
-__global__ __launch_bounds__(WAVE) void k_arcte_lines(PushParams P, LineParams L)
+template <int MODE, int VAR, bool NARROW, bool TAIL, bool PROF = false, int LT = 1, int WPE = 1>
+__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(WPE))) void k_arcte_lines(PushParams P, LineParams L)
 {
     typedef LRowT<LT, NARROW> LRow;
     typedef LSlotT<LT> LSlot;

@@ -15,14 +15,13 @@ def shard_seeds(seeds, world_size, rank):
     return np.ascontiguousarray(np.asarray(seeds, dtype=np.int64)[rank::world_size])
 
 
-def gather_shards(counts, rows, dst=0, group=None):
-    """Gather every rank's column-compressed result on `dst`.
+def gather_shards_begin(counts, rows, dst=0, group=None):
+    """Post the variable-length gather of one result part on `dst` and return a handle for gather_shards_end.
 
     counts: 1-D int64 tensor (community size per local seed), rows: 1-D int32 tensor (their members,
     concatenated).  Both live on the device the process group communicates on (GPU for nccl/RCCL,
-    CPU for gloo).  Returns on dst a list [(counts_k, rows_k) for k in range(world)], None elsewhere.
-    Sizes travel in one all_gather; the payload moves as point-to-point sends to dst only.
-    """
+    CPU for gloo).  Sizes travel in one all_gather; the payload moves as point-to-point sends to dst only, which
+    are in flight when this returns -- the caller may launch its next kernel before it collects them."""
     import torch
     import torch.distributed as dist
 
@@ -32,9 +31,9 @@ def gather_shards(counts, rows, dst=0, group=None):
     all_sizes = [torch.zeros_like(sizes) for _ in range(world)]
     dist.all_gather(all_sizes, sizes, group=group)
     all_sizes = [tuple(int(x) for x in t.tolist()) for t in all_sizes]
+    out, ops = None, []
     if rank == dst:
         out = []
-        ops = []
         for k in range(world):
             if k == dst:
                 out.append((counts, rows))
@@ -46,19 +45,26 @@ def gather_shards(counts, rows, dst=0, group=None):
                 ops.append(dist.P2POp(dist.irecv, ck, k, group))
             if rk.numel():
                 ops.append(dist.P2POp(dist.irecv, rk, k, group))
-        if ops:
-            for req in dist.batch_isend_irecv(ops):
-                req.wait()
-        return out
-    ops = []
-    if counts.numel():
-        ops.append(dist.P2POp(dist.isend, counts, dst, group))
-    if rows.numel():
-        ops.append(dist.P2POp(dist.isend, rows, dst, group))
-    if ops:
-        for req in dist.batch_isend_irecv(ops):
-            req.wait()
-    return None
+    else:
+        if counts.numel():
+            ops.append(dist.P2POp(dist.isend, counts, dst, group))
+        if rows.numel():
+            ops.append(dist.P2POp(dist.isend, rows, dst, group))
+    reqs = dist.batch_isend_irecv(ops) if ops else []
+    # (the tensors of a pending send must stay alive: the handle keeps them)
+    return {"out": out, "reqs": reqs, "keep": (counts, rows), "bytes": sum(8 * a + 4 * b for a, b in all_sizes) - (8 * all_sizes[dst][0] + 4 * all_sizes[dst][1])}
+
+
+def gather_shards_end(handle):
+    """Wait for the transfers of gather_shards_begin: on dst a list [(counts_k, rows_k) for k in range(world)], None elsewhere."""
+    for req in handle["reqs"]:
+        req.wait()
+    return handle["out"]
+
+
+def gather_shards(counts, rows, dst=0, group=None):
+    """Gather every rank's column-compressed result on `dst` (gather_shards_begin + gather_shards_end)."""
+    return gather_shards_end(gather_shards_begin(counts, rows, dst, group))
 
 
 def merge_shards(n, seeds, world_size, gathered):
@@ -113,29 +119,46 @@ def arcte_distributed(adjacency_matrix, rho, epsilon, device=None, group=None, r
         rows_t = torch.from_numpy(np.ascontiguousarray(rows, dtype=np.int32))
         if on_gpu:
             counts_t, rows_t = counts_t.to("cuda:%d" % device), rows_t.to("cuda:%d" % device)
-    else:
-        from reveal_graph_embedding_amd import _native
-        with _native.Context.from_adjacency(adjacency_matrix.indptr, adjacency_matrix.indices, adjacency_matrix.data,
-                                            device=device) as ctx:
-            seeds = ctx.seed_list()
-            ctx.run_seeds(shard_seeds(seeds, world, rank), rho, epsilon, use_effective_epsilon=True)
-            _, total = ctx.result_sizes()
-            if on_gpu:
-                counts_t = torch.from_numpy(np.diff(ctx.colptr())).to("cuda:%d" % device)
-                rows_t = torch.empty(total, dtype=torch.int32, device="cuda:%d" % device)
-                ctx.copy_rows_to_device(rows_t.data_ptr(), total)
-            else:
-                colptr, rows = ctx.fetch()
-                counts_t = torch.from_numpy(np.diff(colptr))
-                rows_t = torch.from_numpy(rows)
-    gathered = gather_shards(counts_t, rows_t, dst=0, group=group)
-    if rank != 0:
-        return None
-    local = merge_shards(n, seeds, world, gathered)
-    identity = sparse.csr_matrix(sparse.eye(n, n, dtype=np.float64))
-    ones = adjacency_matrix.copy()
-    ones.data = np.ones_like(ones.data, dtype=np.float64)
-    return sparse.hstack([identity + ones, local]).tocsr()
+        gathered = gather_shards(counts_t, rows_t, dst=0, group=group)
+        if rank != 0:
+            return None
+        local = merge_shards(n, seeds, world, gathered)
+        identity = sparse.csr_matrix(sparse.eye(n, n, dtype=np.float64))
+        ones = adjacency_matrix.copy()
+        ones.data = np.ones_like(ones.data, dtype=np.float64)
+        return sparse.hstack([identity + ones, local]).tocsr()
+    from reveal_graph_embedding_amd import _native
+    from reveal_graph_embedding_amd.embedding.arcte.arcte import _set_self_loop_values
+    with _native.Context.from_adjacency(adjacency_matrix.indptr, adjacency_matrix.indices, adjacency_matrix.data,
+                                        device=device) as ctx:
+        seeds = ctx.seed_list()
+        mine = np.sort(shard_seeds(seeds, world, rank))
+        ctx.run_seeds(mine, rho, epsilon, use_effective_epsilon=True)
+        _, total = ctx.result_sizes()
+        if on_gpu:
+            counts_t = torch.from_numpy(np.diff(ctx.colptr())).to("cuda:%d" % device)
+            rows_t = torch.empty(total, dtype=torch.int32, device="cuda:%d" % device)
+            ctx.copy_rows_to_device(rows_t.data_ptr(), total)
+        else:
+            colptr, rows = ctx.fetch()
+            counts_t = torch.from_numpy(np.diff(colptr))
+            rows_t = torch.from_numpy(rows)
+        gathered = gather_shards(counts_t, rows_t, dst=0, group=group)
+        if rank != 0:
+            return None
+        # Rank 0's context takes the other ranks' parts where the transport left them (GPU memory under RCCL, host
+        # memory under gloo) and assembles the n x 2n matrix [I + pattern(A) | local] (arcte.py:670-683) on its device:
+        # the reference's sum of worker matrices is a concatenation, every seed owns its column.
+        for k in range(1, world):
+            counts_k, rows_k = gathered[k]
+            part = np.sort(shard_seeds(seeds, world, k))
+            ctx.append_result(part, counts_k.cpu().numpy(), rows_k.data_ptr(), nrows=rows_k.numel())
+        indptr, indices = ctx.fetch_csr(True)
+    index_dtype = np.int32 if max(2 * n, indices.size) < 2 ** 31 else np.int64
+    features = sparse.csr_matrix((np.ones(indices.size, dtype=np.float64), indices.astype(index_dtype, copy=False),
+                                  indptr.astype(index_dtype)), shape=(n, 2 * n))
+    row_of = np.repeat(np.arange(n), np.diff(adjacency_matrix.indptr))
+    return _set_self_loop_values(features, row_of[adjacency_matrix.indices == row_of])
 
 
 def arcte_and_centrality_distributed(adjacency_matrix, rho, epsilon, device=None, group=None, run_block=None):

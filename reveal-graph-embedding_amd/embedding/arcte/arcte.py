@@ -236,40 +236,58 @@ def _arcte_driver(adjacency_matrix, rho, epsilon, number_of_threads, worker):
             features = _features_of_run(ctx, variant, np.sort(ctx.seed_list()), rho, epsilon, True, pattern)
         return _set_self_loop_values(features, self_loops())
 
-    results = [None] * n_gpus
+    # More than one GPU: every worker prepares the graph on its GPU and runs its round-robin chunk of the seed list
+    # (arcte.py:650-666).  The reference's parent then sums the workers' matrices (:670-673); every seed owns its column,
+    # so here the first worker's context takes the others' rows straight from their GPUs (arcte_hip_append_result) and
+    # assembles the whole n x 2n matrix on its device, exactly as the one-GPU path does.
+    contexts = [None] * n_gpus
+    chunks = [None] * n_gpus
     errors = []
 
     def work(k):
         try:
-            with _native.Context.from_adjacency(adjacency_matrix.indptr, adjacency_matrix.indices, adjacency_matrix.data,
-                                                device=devices[k]) as ctx:
-                chunk = roundrobin_chunks(ctx.seed_list(), n_gpus, k)          # arcte.py:650-651
-                if chunk is not None:
-                    results[k] = _features_of_run(ctx, variant, np.sort(np.asarray(chunk, dtype=np.int64)), rho, epsilon,
-                                                  False, None)
+            ctx = _native.Context.from_adjacency(adjacency_matrix.indptr, adjacency_matrix.indices, adjacency_matrix.data,
+                                                 device=devices[k])
+            contexts[k] = ctx
+            chunk = roundrobin_chunks(ctx.seed_list(), n_gpus, k)          # arcte.py:650-651
+            chunks[k] = np.sort(np.asarray(chunk if chunk is not None else [], dtype=np.int64))
+            run_rho = (rho*(0.5))/(1-(0.5*rho)) if variant == _native.LAZY_PAGERANK else rho      # arcte.py:109
+            ctx.run_seeds(chunks[k], run_rho, epsilon, use_effective_epsilon=True, variant=variant, laziness_factor=0.5)
         except BaseException as e:  # surfaced below; the reference drops worker errors silently
             errors.append(e)
 
-    threads = [threading.Thread(target=work, args=(k,)) for k in range(n_gpus)]
-    for t in threads:
-        t.start()
-    for t in threads:
-        t.join()
-    if errors:
-        raise errors[0]
-    results = [x for x in results if x is not None]
-    if results:
-        local_features = results[0]
-        for additive_features in results[1:]:
-            local_features = local_features + additive_features
-        local_features = sparse.csr_matrix(local_features)
-    else:
-        local_features = sparse.csr_matrix((number_of_nodes, number_of_nodes), dtype=np.float64)
-
-    # Form base community feature matrix (arcte.py:676-679).
-    identity_matrix = sparse.csr_matrix(sparse.eye(number_of_nodes, number_of_nodes, dtype=np.float64))
-    base_community_features = identity_matrix + pattern()
-
-    # Stack horizontally matrices to form feature matrix (arcte.py:683).
-    features = sparse.hstack([base_community_features, local_features]).tocsr()
-    return features
+    try:
+        threads = [threading.Thread(target=work, args=(k,)) for k in range(n_gpus)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        if errors:
+            raise errors[0]
+        first = contexts[0]
+        for k in range(1, n_gpus):
+            _, total = contexts[k].result_sizes()
+            first.append_result(chunks[k], np.diff(contexts[k].colptr()), contexts[k].result_device_rows(), nrows=total)
+            contexts[k].close()
+            contexts[k] = None
+        ones = _OnesInBackground(first.result_csr_size(True))
+        try:
+            indptr, indices = first.fetch_csr(True)
+        except _native.ArcteHipError as e:
+            ones.result()
+            if e.code != -3:                      # ARCTE_HIP_ECAPACITY: too many entries for the device assembly
+                raise
+            colptr, rows = first.fetch()
+            seeds_all = np.concatenate(chunks)
+            local = _seed_matrix(number_of_nodes, seeds_all, colptr, rows)
+            base = sparse.csr_matrix(sparse.eye(number_of_nodes, number_of_nodes, dtype=np.float64)) + pattern()
+            return sparse.hstack([base, local]).tocsr()                  # arcte.py:676-683
+    finally:
+        for ctx in contexts:
+            if ctx is not None:
+                ctx.close()
+    width = 2 * number_of_nodes
+    index_dtype = np.int32 if max(width, indices.size) < 2 ** 31 else np.int64
+    features = sparse.csr_matrix((ones.result()[:indices.size], indices.astype(index_dtype, copy=False), indptr.astype(index_dtype)),
+                                 shape=(number_of_nodes, width))
+    return _set_self_loop_values(features, self_loops())

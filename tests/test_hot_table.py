@@ -1,9 +1,10 @@
-"""The LDS-resident hot table of the push kernel must be invisible in the results.
+"""The LDS-resident hot table of the push kernels must be invisible in the results.
 
-The state of the highest-degree nodes lives in LDS (one value per node while r == s, moved to the dense HBM state
-when the node is pushed).  Whatever the table size -- off, a handful of nodes (hot and cold targets mixed inside
-one tile), every node on chip -- communities, push counts and work counters must equal the oracle's, for the three
-push flavours and both arithmetic types (float32 against its own table-off run)."""
+The state of the highest-degree nodes lives in LDS (one value per node while r == s, moved to the pushed-state array --
+line state -- or to the dense HBM entry -- dense state -- when the node is pushed).  Whatever the table size -- off, a
+handful of nodes (hot and cold targets mixed inside one tile), every node on chip -- communities, push counts and work
+counters must equal the oracle's, for the three push flavours, both state layouts (ARCTE_HIP_STATE) and both arithmetic
+types (float32 against its own table-off run).  tests/test_line_state.py holds the line state's own levels."""
 import numpy as np
 import pytest
 
@@ -16,9 +17,13 @@ GRAPHS = ["ba300", "grid25", "corner", "weighted", "selfloop", "directed", "rmat
 FLAVOURS = [oracle.ARCTE, oracle.PAGERANK, oracle.LAZY_PAGERANK]
 
 
-def run(g, cap, variant, monkeypatch, float32=False, warm=None, **kw):
+def run(g, cap, variant, monkeypatch, float32=False, warm=None, state=None, **kw):
     from reveal_graph_embedding_amd import _native
     monkeypatch.setenv("ARCTE_HIP_HOT", str(cap))
+    if state is None:
+        monkeypatch.delenv("ARCTE_HIP_STATE", raising=False)
+    else:
+        monkeypatch.setenv("ARCTE_HIP_STATE", state)
     if warm is None:
         monkeypatch.delenv("ARCTE_HIP_WARM", raising=False)
     else:
@@ -32,6 +37,8 @@ def run(g, cap, variant, monkeypatch, float32=False, warm=None, **kw):
                       variant=variant, laziness_factor=0.5)
         colptr, rows, nop = ctx.fetch(want_nop=True)
         st = ctx.stats()
+        if state is not None and not float32:
+            assert ctx.state_info()["line_state"] == (1 if state == "lines" else 0)
     return colptr, rows, nop, [st["pushes"], st["edges"], st["enqueues"], st["support"]]
 
 
@@ -40,9 +47,10 @@ def sorted_rows(colptr, rows):
     return rows[np.lexsort((rows, seg))]
 
 
+@pytest.mark.parametrize("state", ["lines", "dense"])
 @pytest.mark.parametrize("name", GRAPHS)
 @pytest.mark.parametrize("variant", FLAVOURS)
-def test_every_table_size_matches_the_oracle(name, variant, monkeypatch):
+def test_every_table_size_matches_the_oracle(name, variant, state, monkeypatch):
     g = load_golden(name)
     w = g["w"]
     o_colptr, o_rows, _, o_nop, o_stats = oracle.worker(w, g["out_degree"], g["in_degree"], g["all_seeds"], g["rho"],
@@ -50,8 +58,8 @@ def test_every_table_size_matches_the_oracle(name, variant, monkeypatch):
     # (LDS table size, warm-table end rank): off; LDS only; LDS + warm + dense mixed inside one tile; no LDS share but
     # warm; everything in LDS / warm (the defaults on a graph this small)
     for cap, warm in ((0, 0), (4, 0), (4, 24), (32, 100), (4, None), (-1, None)):
-        colptr, rows, nop, stats = run(g, cap, variant, monkeypatch, warm=warm)
-        tag = "hot cap %d, warm end %s" % (cap, warm)
+        colptr, rows, nop, stats = run(g, cap, variant, monkeypatch, warm=warm, state=state)
+        tag = "%s state, hot cap %d, warm end %s" % (state, cap, warm)
         assert np.array_equal(colptr, o_colptr), tag
         assert np.array_equal(nop, o_nop), tag
         assert np.array_equal(sorted_rows(colptr, rows), o_rows), tag
@@ -63,11 +71,11 @@ def test_launch_shapes(shape, monkeypatch):
     """One wavefront per CU with the whole LDS, many, and the default; two wavefronts per workgroup."""
     g = load_golden("rmat2000")
     ref = run(g, 0, oracle.ARCTE, monkeypatch, **shape)
-    for wpb in ("1", "2", "4"):
+    for wpb, state in (("1", "lines"), ("1", "dense"), ("2", "dense"), ("4", "dense")):
         monkeypatch.setenv("ARCTE_HIP_WAVES_PER_BLOCK", wpb)
-        for tiles in ("2", "4"):
+        for tiles in ("1", "2", "4"):
             monkeypatch.setenv("ARCTE_HIP_TILES", tiles)
-            got = run(g, -1, oracle.ARCTE, monkeypatch, **shape)
+            got = run(g, -1, oracle.ARCTE, monkeypatch, state=state, **shape)
             assert np.array_equal(got[0], ref[0]) and np.array_equal(got[2], ref[2]) and got[3] == ref[3]
             assert np.array_equal(sorted_rows(got[0], got[1]), sorted_rows(ref[0], ref[1]))
 

@@ -1,0 +1,113 @@
+"""The line state of the propagation kernel (csrc/arcte_lines.hpp) must be invisible in the results.
+
+Nodes are named by rank inside the kernel; ranks below K keep their value in LDS, ranks below 8 M in strided 64-byte
+lines whose touched-bits are an LDS bitmap (first touch = blind whole-line write), the ranks beyond in lines whose
+touched-bits live in global memory (region B); pushed nodes move to a compact {r, s} array.  Whatever the split --
+everything on chip, nothing on chip, region B forced onto a 300-node graph -- communities, push counts and work
+counters equal the oracle's, for the three push flavours and for arcte_and_centrality."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from oracle import oracle
+from test_hot_table import sorted_rows
+
+pytestmark = pytest.mark.gpu
+
+GRAPHS = ["ba300", "grid25", "corner", "weighted", "selfloop", "directed", "rmat2000", "ws1000", "ba1500"]
+FLAVOURS = [oracle.ARCTE, oracle.PAGERANK, oracle.LAZY_PAGERANK]
+# (values of the LDS level, lines with touched-bits in LDS): nothing on chip and every rank >= 512 in region B; a handful
+# of on-chip values inside the tiles; a mid-size split; the defaults (a graph this small lives on chip entirely)
+SPLITS = [(0, 64), (4, 64), (24, 128), (-1, None)]
+
+
+def run(g, hot, lines_lds, variant, monkeypatch, **kw):
+    from reveal_graph_embedding_amd import _native
+    monkeypatch.setenv("ARCTE_HIP_HOT", str(hot))
+    monkeypatch.delenv("ARCTE_HIP_STATE", raising=False)
+    if lines_lds is None:
+        monkeypatch.delenv("ARCTE_HIP_LINES_LDS", raising=False)
+    else:
+        monkeypatch.setenv("ARCTE_HIP_LINES_LDS", str(lines_lds))
+    w = g["w"]
+    rho = g["rho"]
+    with _native.Context(w.indptr, w.indices, w.data, g["out_degree"], g["in_degree"], **kw) as ctx:
+        ctx.run_seeds(g["all_seeds"], (rho * 0.5) / (1 - 0.5 * rho) if variant == oracle.LAZY_PAGERANK else rho, g["epsilon"],
+                      variant=variant, laziness_factor=0.5)
+        colptr, rows, nop = ctx.fetch(want_nop=True)
+        st = ctx.stats()
+        info = ctx.state_info()
+    return colptr, rows, nop, st, info
+
+
+@pytest.mark.parametrize("name", GRAPHS)
+@pytest.mark.parametrize("variant", FLAVOURS)
+def test_every_split_matches_the_oracle(name, variant, monkeypatch):
+    g = load_golden(name)
+    o_colptr, o_rows, _, o_nop, o_stats = oracle.worker(g["w"], g["out_degree"], g["in_degree"], g["all_seeds"], g["rho"],
+                                                        g["epsilon"], want_stats=True, variant=variant)
+    for hot, lines_lds in SPLITS:
+        colptr, rows, nop, st, info = run(g, hot, lines_lds, variant, monkeypatch)
+        tag = "%d on-chip values, %s lines in LDS" % (hot, lines_lds)
+        assert info["line_state"] == 1, tag
+        if lines_lds is not None and g["n"] > 8 * lines_lds:
+            assert info["lines_region_b"] > 0, tag
+        assert np.array_equal(colptr, o_colptr), tag
+        assert np.array_equal(nop, o_nop), tag
+        assert np.array_equal(sorted_rows(colptr, rows), o_rows), tag
+        assert [st["pushes"], st["edges"], st["enqueues"], st["support"]] == list(o_stats), tag
+        # every traversed edge is exactly one update of one of the four kinds
+        assert info["lds_updates"] + info["blind_line_writes"] + info["line_read_modify_writes"] + info["pushed_node_updates"] == st["edges"], tag
+        if hot == 0:
+            assert info["lds_updates"] == 0 and info["blind_line_writes"] > 0, tag
+
+
+def test_small_capacities_grow_and_rerun(monkeypatch):
+    """A pushed-state array, a candidate list and a ring that are too small flag the seed; the host grows them by four
+    and runs it again: nothing is dropped."""
+    g = load_golden("rmat2000")
+    o_colptr, o_rows, _, o_nop, _ = oracle.worker(g["w"], g["out_degree"], g["in_degree"], g["all_seeds"], g["rho"], g["epsilon"],
+                                                  want_stats=True)
+    monkeypatch.setenv("ARCTE_HIP_PUSHED", "64")
+    monkeypatch.setenv("ARCTE_HIP_CANDIDATES", "64")
+    colptr, rows, nop, st, info = run(g, 4, 64, oracle.ARCTE, monkeypatch, queue_capacity=64)
+    assert st["reruns"] > 0 and st["launches"] > 1
+    assert info["pushed_capacity"] > 64 or info["candidate_capacity"] > 64
+    assert np.array_equal(colptr, o_colptr) and np.array_equal(nop, o_nop)
+    assert np.array_equal(sorted_rows(colptr, rows), o_rows)
+
+
+def test_centrality_with_region_b(monkeypatch):
+    """arcte_and_centrality's seed loop (every node a seed, the whole support a candidate) through every level."""
+    from reveal_graph_embedding_amd import _native
+    from test_centrality_weighting_cpu import load_centrality
+    g = load_centrality("ba300")
+    a = g["adjacency"]
+    out = []
+    for hot, lines_lds in ((-1, None), (0, 64), (8, 64)):
+        monkeypatch.setenv("ARCTE_HIP_HOT", str(hot))
+        if lines_lds is None:
+            monkeypatch.delenv("ARCTE_HIP_LINES_LDS", raising=False)
+        else:
+            monkeypatch.setenv("ARCTE_HIP_LINES_LDS", str(lines_lds))
+        with _native.Context.from_adjacency(a.indptr, a.indices, a.data) as ctx:
+            ctx.run_centrality(float(g["rho"]), float(g["epsilon"]))
+            colptr, rows = ctx.fetch()
+            out.append((colptr, sorted_rows(colptr, rows), ctx.centrality()))
+    np.testing.assert_array_equal(out[0][2], g["centrality"])            # the reference's own vector, bit for bit
+    for colptr, rows, cent in out[1:]:
+        assert np.array_equal(colptr, out[0][0]) and np.array_equal(rows, out[0][1])
+        assert np.array_equal(cent, out[0][2])
+
+
+def test_consecutive_contexts_get_the_same_slots():
+    """Buffers parked in the process-wide cache count as free when the slot count is chosen (round-2 advisor finding)."""
+    from reveal_graph_embedding_amd import _native
+    g = load_golden("rmat2000")
+    w = g["w"]
+    slots = []
+    for _ in range(3):
+        with _native.Context(w.indptr, w.indices, w.data, g["out_degree"], g["in_degree"]) as ctx:
+            ctx.run_seeds(g["all_seeds"][:50], g["rho"], g["epsilon"])
+            slots.append(ctx.info()["slots"])
+    assert slots[0] == slots[1] == slots[2]

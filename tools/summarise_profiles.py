@@ -32,7 +32,7 @@ def main():
     for path in glob.glob(os.path.join(PROF, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
         with open(path) as f:
             for row in csv.DictReader(f):
-                if "k_arcte_seeds" not in row["Kernel_Name"]:
+                if "k_arcte_seeds" not in row["Kernel_Name"] and "k_arcte_lines" not in row["Kernel_Name"]:
                     continue
                 c = counters.setdefault(row["Counter_Name"], {"launches": 0, "sum": 0.0, "kernel": row["Kernel_Name"],
                                                               "lds": row["LDS_Block_Size"], "vgpr": row["VGPR_Count"]})
@@ -42,7 +42,7 @@ def main():
     any_c = next(iter(counters.values()), None)
     meta = {"kernel": any_c["kernel"] if any_c else None, "LDS_Block_Size": any_c["lds"] if any_c else None,
             "VGPR_Count": any_c["vgpr"] if any_c else None, "kernel_source_id": kernel_source_id(), "commit": commit, "workload": key}
-    with open(os.path.join(out_dir, "bench_n1_pmc_k_arcte_seeds.json"), "w") as f:
+    with open(os.path.join(out_dir, "bench_n1_pmc_propagation_kernel.json"), "w") as f:
         json.dump({"meta": meta, "counters": summary}, f, indent=1, sort_keys=True)
     for name in ("trace.json",):
         src = os.path.join(PROF, name)
@@ -55,11 +55,11 @@ def main():
         table = json.load(open(path)) if os.path.exists(path) else {}
         table[key] = {"hbm_bytes_per_launch": fetch + write, "fetch_bytes": fetch, "write_bytes": write, "kernel": meta["kernel"],
                       "kernel_source_id": meta["kernel_source_id"], "commit": commit,
-                      "source": os.path.relpath(os.path.join(out_dir, "bench_n1_pmc_k_arcte_seeds.json"), ROOT),
-                      "note": "FETCH_SIZE/WRITE_SIZE in KiB from separate rocprofv3 --pmc passes, x1024, no further correction: "
-                              "calibrated on this access pattern in profiles/r01/calibration_fetch_write_size.txt (one 64-B read "
-                              "request per random 32-B entry gather, one 32-B sector per modified entry); the gfx950 x2 read-side "
-                              "correction applies only to the coalesced CSR stream (a minority of this kernel's read requests)"}
+                      "source": os.path.relpath(os.path.join(out_dir, "bench_n1_pmc_propagation_kernel.json"), ROOT),
+                      "note": "FETCH_SIZE/WRITE_SIZE in KiB from separate rocprofv3 --pmc passes, x1024 (random 8-byte state reads are "
+                              "one 64-byte request each and are counted as they are: profiles/r01/calibration_fetch_write_size.txt); "
+                              "bench.py adds the half of the coalesced row stream that FETCH_SIZE under-reports on gfx950 "
+                              "(/opt/skills/guides/MI355X_MICROARCH.md) and says so in roofline.traffic_note"}
         with open(path, "w") as f:
             json.dump(table, f, indent=1, sort_keys=True)
     print(json.dumps({"meta": meta, "counters": summary}, indent=1, sort_keys=True))
