@@ -184,6 +184,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(WPE))) voi
         unsigned long long nedges = 0;
         bool ok = true, runaway = false;
         int32_t fail_status = ST_QUEUE_OVERFLOW;
+        unsigned long long s_lds = 0, s_blind = 0, s_rmw = 0, s_moved = 0;   // this seed's updates by kind (counted when it completes)
 
         auto load_row = [&](int64_t base, int64_t re, double w_row, LRow &R) {
 #pragma unroll
@@ -293,10 +294,10 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(WPE))) voi
                         else if (rk < K) hot[rk] = r_new;
                         else if (!E.owner[t]) vals[value_index(rk)] = r_new;
                     }
-                    c_moved += __popcll(__ballot(mv));
-                    c_lds += __popcll(__ballot(act && !mv && rk < K));
-                    c_blind += __popcll(__ballot(act && E.owner[t]));
-                    c_rmw += __popcll(__ballot(act && !mv && rk >= K && !E.owner[t]));
+                    s_moved += __popcll(__ballot(mv));
+                    s_lds += __popcll(__ballot(act && !mv && rk < K));
+                    s_blind += __popcll(__ballot(act && E.owner[t]));
+                    s_rmw += __popcll(__ballot(act && !mv && rk >= K && !E.owner[t]));
                     if (VAR == 0) {
                         // candidate list (see k_arcte_seeds): nodes whose s/in_degree has reached a lower bound of the final threshold
                         const double bar = cand_thr * dv;
@@ -647,6 +648,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(WPE))) voi
             P.out_off[pos] = (int64_t)off;
             P.nop[pos] = npush;
             if (sta == ST_OK) {
+                c_lds += s_lds; c_blind += s_blind; c_rmw += s_rmw; c_moved += s_moved;
                 atomicAdd(&P.stats[0], (unsigned long long)npush);
                 atomicAdd(&P.stats[1], nedges);
                 atomicAdd(&P.stats[2], (unsigned long long)tail);
