@@ -297,6 +297,31 @@ int arcte_hip_peak_snr_weights(int device, int64_t n_classes, int64_t n_cols, co
  * zeros are eliminated, rows are l2-normalised. */
 int arcte_hip_features_community_weighting(arcte_hip_features *f, const double *community_weights);
 
+/*
+ * The file formats either side of the path (entry_points/arcte.py:63-84), natively.
+ *
+ * arcte_hip_edge_list_read replaces read_adjacency_matrix (datautil/datarw.py:54-120) up to the scipy wrapper: every
+ * line is `line.strip().split(separator)` (common.py:36-49); a line whose first field begins with '#' is skipped;
+ * fields 0 / 1 are the integer node ids, field 2 the float weight; ids are renumbered in first-seen order, source before
+ * target (:87-92); with `undirected` every non-loop edge is followed by its reciprocal (:105-109); duplicate edges stay
+ * duplicate triplets (arcte_hip_create_from_coo sums them like csr_matrix(coo) does).  A malformed line fails with
+ * ARCTE_HIP_EINVAL and its line number (the reference raises ValueError / IndexError there).  No GPU involved.
+ * _sizes gives the number of nodes and of triplets, _fetch copies them out (row / col int32, val float64, node_ids[new
+ * id] = original id: the reference's node_to_id; any pointer may be NULL), _destroy frees the list.
+ */
+typedef struct arcte_hip_edge_list arcte_hip_edge_list;
+int arcte_hip_edge_list_read(const char *path, const char *separator, int undirected, arcte_hip_edge_list **out);
+int arcte_hip_edge_list_sizes(arcte_hip_edge_list *el, int64_t *n_nodes, int64_t *n_triplets);
+int arcte_hip_edge_list_fetch(arcte_hip_edge_list *el, int32_t *row, int32_t *col, double *val, int64_t *node_ids);
+int arcte_hip_edge_list_destroy(arcte_hip_edge_list *el);
+/* write_features (datautil/datarw.py:123-143) for arcte()'s matrix given as CSR arrays (what
+ * arcte_hip_fetch_result_csr returns): one line per stored entry in row-major order,
+ * `<node_ids[row]><separator><column><separator><int(value)>`; every value is 1 except the diagonal entry of the nodes
+ * listed in doubled_diagonal, which is 2 (identity + ones on a self-loop, embedding/arcte/arcte.py:676-679). */
+int arcte_hip_write_feature_triplets(const char *path, int64_t n_rows, const int64_t *indptr, const int32_t *indices,
+                                     const int64_t *node_ids, const int64_t *doubled_diagonal, int64_t n_doubled,
+                                     const char *separator);
+
 /* The reference's parent process SUMS its workers' n x n matrices (embedding/arcte/arcte.py:670-673); every seed owns
  * its column, so the sum is a concatenation.  This entry appends another worker's result -- its seeds, their community
  * sizes and the members (int32 node ids, concatenated; `rows` may point to host memory or to memory of any GPU of this

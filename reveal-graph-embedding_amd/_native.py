@@ -58,6 +58,11 @@ SIGNATURES = {
     "arcte_hip_set_float32": (C.c_int, [C.c_void_p, C.c_int]),
     "arcte_hip_stream_bandwidth": (C.c_int, [C.c_int, C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "arcte_hip_append_result": (C.c_int, [C.c_void_p, _i64p, _i64p, C.c_int64, C.c_void_p, C.c_int64]),
+    "arcte_hip_edge_list_read": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]),
+    "arcte_hip_edge_list_sizes": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "arcte_hip_edge_list_fetch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "arcte_hip_edge_list_destroy": (C.c_int, [C.c_void_p]),
+    "arcte_hip_write_feature_triplets": (C.c_int, [C.c_char_p, C.c_int64, _i64p, C.c_void_p, _i64p, _i64p, C.c_int64, C.c_char_p]),
     "arcte_hip_info": (C.c_int, [C.c_void_p, _i64p]),
     "arcte_hip_state_info": (C.c_int, [C.c_void_p, _i64p]),
     "arcte_hip_launch_occupancy": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
@@ -135,6 +140,34 @@ def stream_bandwidth(device=0, nbytes=4 << 30):
     rd, cp = C.c_double(0), C.c_double(0)
     _check(lib().arcte_hip_stream_bandwidth(int(device), int(nbytes), C.byref(rd), C.byref(cp)))
     return rd.value, cp.value
+
+
+def read_edge_list(file_path, separator, undirected):
+    """The edge list as flat arrays (arcte_hip_edge_list_read: datautil/datarw.py:54-120 natively):
+    (number_of_nodes, row int32, col int32, data float64, node_ids int64 with node_ids[new id] = original id)."""
+    h = C.c_void_p()
+    _check(lib().arcte_hip_edge_list_read(str(file_path).encode(), str(separator).encode(), 1 if undirected else 0, C.byref(h)))
+    try:
+        n, m = C.c_int64(0), C.c_int64(0)
+        _check(lib().arcte_hip_edge_list_sizes(h, C.byref(n), C.byref(m)))
+        row = np.empty(m.value, dtype=np.int32)
+        col = np.empty(m.value, dtype=np.int32)
+        val = np.empty(m.value, dtype=np.float64)
+        ids = np.empty(n.value, dtype=np.int64)
+        _check(lib().arcte_hip_edge_list_fetch(h, row.ctypes.data, col.ctypes.data, val.ctypes.data, ids.ctypes.data))
+    finally:
+        lib().arcte_hip_edge_list_destroy(h)
+    return int(n.value), row, col, val, ids
+
+
+def write_feature_triplets(file_path, indptr, indices, node_ids, doubled_diagonal_nodes, separator):
+    """arcte()'s matrix as `<original id><sep><column><sep><value>` lines (arcte_hip_write_feature_triplets)."""
+    indptr = np.ascontiguousarray(indptr, dtype=np.int64)
+    indices = np.ascontiguousarray(indices, dtype=np.int32)
+    node_ids = np.ascontiguousarray(node_ids, dtype=np.int64)
+    doubled = np.ascontiguousarray(doubled_diagonal_nodes, dtype=np.int64).reshape(-1)
+    _check(lib().arcte_hip_write_feature_triplets(str(file_path).encode(), int(indptr.size - 1), indptr, indices.ctypes.data, node_ids,
+                                                  doubled, int(doubled.size), str(separator).encode()))
 
 
 def fastest_context(make, calibrate, tries=3):

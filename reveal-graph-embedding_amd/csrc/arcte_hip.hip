@@ -689,6 +689,47 @@ int rank_nodes(arcte_hip_ctx *c, DevBuf<uint32_t> &count)
     return rk;
 }
 
+// The caller's CSR arrays as they arrived on the device (arcte_hip_create: the arcte_worker seam): every column index
+// inside [0, n), no column stored twice in a row -- the lanes of a push own one target each (push.py:62-64 on a CSR
+// row), a repeated column would make two of them race; scipy's sum_duplicates() (or get_natural_random_walk_matrix)
+// removes them.  The row ORDER is the caller's and stays: it is the FIFO's enqueue order (similarity.py:194-196).
+int validate_rows_on_device(arcte_hip_ctx *c)
+{
+    const int64_t n = c->n, nnz = c->nnz;
+    DevBuf<int32_t> flags;
+    DevBuf<uint64_t> keys_in, keys_out;
+    DevBuf<char> temp;
+    int rc = [&]() -> int {
+        int32_t fl[2] = {0, 0};
+        HIP_TRY(flags.alloc(2));
+        HIP_TRY(hipMemsetAsync(flags.p, 0, 2 * sizeof(int32_t), c->stream));
+        const int row_blocks = (int)((n + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
+        hipLaunchKernelGGL(k_check_rows, dim3(row_blocks), dim3(BLOCK), 0, c->stream, c->indptr.p, c->indices.p, n, flags.p);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(fl, flags.p, sizeof(fl), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (fl[0]) return fail(ARCTE_HIP_EINVAL, "column index out of range");
+        if (!fl[1] || nnz < 2) return 0;               // every row strictly ascending: no duplicates
+        // some row is not ascending: unsorted (fine) or a repeated column -- sort a copy of the (row, column) keys
+        HIP_TRY(keys_in.alloc(nnz));
+        HIP_TRY(keys_out.alloc(nnz));
+        hipLaunchKernelGGL(k_csr_keys, dim3(row_blocks), dim3(BLOCK), 0, c->stream, c->indptr.p, c->indices.p, n, keys_in.p);
+        size_t tb = 0;
+        HIP_TRY(hipcub::DeviceRadixSort::SortKeys(nullptr, tb, keys_in.p, keys_out.p, (size_t)nnz, 0, 64, c->stream));
+        HIP_TRY(temp.alloc(tb));
+        HIP_TRY(hipcub::DeviceRadixSort::SortKeys(temp.p, tb, keys_in.p, keys_out.p, (size_t)nnz, 0, 64, c->stream));
+        HIP_TRY(hipMemsetAsync(flags.p, 0, 2 * sizeof(int32_t), c->stream));
+        hipLaunchKernelGGL(k_adjacent_equal, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, c->stream, keys_out.p, nnz, flags.p);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(fl, flags.p, sizeof(fl), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (fl[0]) return fail(ARCTE_HIP_EINVAL, "a row stores the same column twice (call sum_duplicates() first)");
+        return 0;
+    }();
+    flags.release(); keys_in.release(); keys_out.release(); temp.release();
+    return rc;
+}
+
 // Slots of the dense-state kernel.  Its launch shape: the kernel is bound by the chip's random-access rate into the
 // per-slot HBM state, and the LDS-resident hot table takes 20-40 % of those accesses away -- the more the fewer
 // wavefronts share a CU's LDS, while fewer wavefronts keep fewer accesses in flight (interleaved A/B on the 1M/50M graph,
@@ -944,6 +985,9 @@ int transition_on_device(arcte_hip_ctx *c)
 
 }  // namespace
 
+// (arcte_io.cpp reports its errors through the same thread-local message)
+extern "C" __attribute__((visibility("hidden"))) int arcte_io_set_error(int code, const char *msg) { return fail(code, msg ? msg : ""); }
+
 extern "C" {
 
 int arcte_hip_abi_version(void) { return 8; }
@@ -975,19 +1019,6 @@ int arcte_hip_create(int device, int64_t n, int64_t nnz, const int64_t *indptr, 
     if (indptr[0] != 0 || indptr[n] != nnz) return fail(ARCTE_HIP_EINVAL, "indptr does not span [0, nnz]");
     for (int64_t i = 0; i < n; i++)
         if (indptr[i + 1] < indptr[i]) return fail(ARCTE_HIP_EINVAL, "indptr is not monotone");
-    for (int64_t k = 0; k < nnz; k++)
-        if (indices[k] < 0 || indices[k] >= n) return fail(ARCTE_HIP_EINVAL, "column index out of range");
-    {
-        // the lanes of a push own one target each (push.py:62-64 on a CSR row): a column stored twice in a row
-        // would race; scipy's sum_duplicates() (or get_natural_random_walk_matrix) removes them
-        std::vector<int64_t> last_row((size_t)n, -1);
-        for (int64_t i = 0; i < n; i++)
-            for (int64_t k = indptr[i]; k < indptr[i + 1]; k++) {
-                if (last_row[(size_t)indices[k]] == i)
-                    return fail(ARCTE_HIP_EINVAL, "row " + std::to_string(i) + " stores column " + std::to_string(indices[k]) + " twice");
-                last_row[(size_t)indices[k]] = i;
-            }
-    }
     arcte_hip_ctx *c = nullptr;
     int rc = ctx_begin(device, n, nnz, &c);
     if (rc) return rc;
@@ -1001,6 +1032,8 @@ int arcte_hip_create(int device, int64_t n, int64_t nnz, const int64_t *indptr, 
         }
         HIP_TRY(hipMemcpyAsync(c->out_degree.p, out_degree, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipMemcpyAsync(c->in_degree.p, in_degree, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        int rv = validate_rows_on_device(c);
+        if (rv) return rv;
         return ctx_finish(c, n_slots, queue_capacity);
     }();
     if (rc) {

@@ -91,14 +91,20 @@ struct EpsShared {
     PwFrame frames[40];
 };
 
-// numpy pairwise leaf (n <= 128) over a[i] = out_degree[indices[lo + i]]; also folds min/max of a.
-__device__ double pw_leaf(const GraphDev &g, int64_t lo, int64_t n, double *leaf, int lane, double &amin, double &amax)
+// numpy's pairwise float64 sum (oracle: np_pairwise) of a[lo .. lo + n), a[k] = at(k), by one wavefront.  One
+// evaluator for both users: the neighbour-degree mean of calculate_epsilon_effective (at(k) = out_degree[indices[k]],
+// min/max of a folded in: MINMAX) and the row sums of get_natural_random_walk_matrix (arcte_prepare.hpp: a plain array).
+// Leaf (n <= 128): numpy's eight strided partial sums, combined pairwise, then the remainder left to right.
+template <bool MINMAX, typename At>
+__device__ double pw_leaf_t(At at, int64_t lo, int64_t n, double *leaf, int lane, double &amin, double &amax)
 {
     for (int i = lane; i < n; i += WAVE) {
-        double a = g.out_degree[g.indices[lo + i]];
+        const double a = at(lo + i);
         leaf[i] = a;
-        amin = (a < amin) ? a : amin;
-        amax = (a > amax) ? a : amax;
+        if (MINMAX) {
+            amin = (a < amin) ? a : amin;
+            amax = (a > amax) ? a : amax;
+        }
     }
     // same-wave LDS write -> read: the DS queue is in order, the compiler keeps the dependency
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -122,9 +128,9 @@ __device__ double pw_leaf(const GraphDev &g, int64_t lo, int64_t n, double *leaf
     return res;
 }
 
-// numpy's pairwise float64 sum (oracle: np_pairwise) of a[i] = out_degree[indices[lo + i]], i < n, by one
-// wavefront: the recursion is evaluated with an explicit frame stack in LDS; min/max of a are folded in.
-__device__ double pw_sum_wave(const GraphDev &g, int64_t lo, int64_t n, EpsShared &S, int lane, double &amin, double &amax)
+// the recursion above the leaves, evaluated with an explicit frame stack in LDS
+template <bool MINMAX, typename At>
+__device__ double pw_sum_wave_t(At at, int64_t lo, int64_t n, EpsShared &S, int lane, double &amin, double &amax)
 {
     int sp = 0;
     double ret = 0.0;
@@ -135,7 +141,7 @@ __device__ double pw_sum_wave(const GraphDev &g, int64_t lo, int64_t n, EpsShare
         const int64_t fn = S.frames[sp].n;
         const int stage = S.frames[sp].stage;
         if (fn <= 128) {
-            ret = pw_leaf(g, flo, fn, S.leaf, lane, amin, amax);
+            ret = pw_leaf_t<MINMAX>(at, flo, fn, S.leaf, lane, amin, amax);
             sp--;
             continue;
         }
@@ -161,6 +167,19 @@ __device__ double pw_sum_wave(const GraphDev &g, int64_t lo, int64_t n, EpsShare
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     }
     return ret;
+}
+
+// a[i] = out_degree[indices[lo + i]], min/max of a folded in
+__device__ double pw_sum_wave(const GraphDev &g, int64_t lo, int64_t n, EpsShared &S, int lane, double &amin, double &amax)
+{
+    return pw_sum_wave_t<true>([&](int64_t k) -> double { return g.out_degree[g.indices[k]]; }, lo, n, S, lane, amin, amax);
+}
+
+// a plain array
+__device__ double pw_sum_plain(const double *a, int64_t lo, int64_t n, EpsShared &S, int lane)
+{
+    double unused_min = 0.0, unused_max = 0.0;
+    return pw_sum_wave_t<false>([&](int64_t k) -> double { return a[k]; }, lo, n, S, lane, unused_min, unused_max);
 }
 
 // arcte.py:32-48 from the reduced neighbour degrees

@@ -15,69 +15,7 @@
 
 namespace {
 
-// ---- numpy pairwise sum of a[lo .. lo+n) by one wavefront (same evaluation as pw_sum_wave, plain array) -------
-__device__ double pw_leaf_plain(const double *a, int64_t lo, int64_t n, double *leaf, int lane)
-{
-    for (int i = lane; i < n; i += WAVE) leaf[i] = a[lo + i];
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    double res;
-    if (n < 8) {
-        res = 0.0;
-        for (int i = 0; i < n; i++) res += leaf[i];
-    } else {
-        int64_t nfull = n - (n % 8);
-        double r = 0.0;
-        if (lane < 8) {
-            r = leaf[lane];
-            for (int64_t i = 8 + lane; i < nfull; i += 8) r += leaf[i];
-        }
-        double r0 = shfl_f64(r, 0), r1 = shfl_f64(r, 1), r2 = shfl_f64(r, 2), r3 = shfl_f64(r, 3);
-        double r4 = shfl_f64(r, 4), r5 = shfl_f64(r, 5), r6 = shfl_f64(r, 6), r7 = shfl_f64(r, 7);
-        res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
-        for (int64_t i = nfull; i < n; i++) res += leaf[i];
-    }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    return res;
-}
-
-__device__ double pw_sum_plain(const double *a, int64_t lo, int64_t n, EpsShared &S, int lane)
-{
-    int sp = 0;
-    double ret = 0.0;
-    if (lane == 0) { S.frames[0].lo = lo; S.frames[0].n = n; S.frames[0].stage = 0; }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    while (sp >= 0) {
-        const int64_t flo = S.frames[sp].lo;
-        const int64_t fn = S.frames[sp].n;
-        const int stage = S.frames[sp].stage;
-        if (fn <= 128) {
-            ret = pw_leaf_plain(a, flo, fn, S.leaf, lane);
-            sp--;
-            continue;
-        }
-        int64_t n2 = fn / 2;
-        n2 -= n2 % 8;
-        if (stage == 0) {
-            if (lane == 0) {
-                S.frames[sp].stage = 1;
-                S.frames[sp + 1].lo = flo; S.frames[sp + 1].n = n2; S.frames[sp + 1].stage = 0;
-            }
-            sp++;
-        } else if (stage == 1) {
-            if (lane == 0) {
-                S.frames[sp].left = ret;
-                S.frames[sp].stage = 2;
-                S.frames[sp + 1].lo = flo + n2; S.frames[sp + 1].n = fn - n2; S.frames[sp + 1].stage = 0;
-            }
-            sp++;
-        } else {
-            ret = S.frames[sp].left + ret;
-            sp--;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    }
-    return ret;
-}
+// (the numpy pairwise sum of a plain array by one wavefront is pw_sum_plain in arcte_kernels.hpp: one evaluator for both users)
 
 // transition.py:55 + :58: out_degree[i] = A.sum(axis=1)[i] (np.add.reduceat order), zero -> 1.  One wavefront per row.
 __global__ __launch_bounds__(BLOCK) void k_out_degree(const int64_t *indptr, const double *data, int64_t n, double *out_degree)
@@ -116,6 +54,13 @@ __global__ __launch_bounds__(BLOCK) void k_row_scale(const int64_t *indptr, cons
     if (i >= n) return;
     const double d = out_degree[i];
     for (int64_t k = indptr[i] + lane; k < indptr[i + 1]; k += WAVE) data[k] = data[k] / d;
+}
+
+// sorted (row << 32 | column) keys: flag[0] = 1 when two neighbours are equal (a row stores a column twice)
+__global__ void k_adjacent_equal(const uint64_t *keys, int64_t m, int32_t *flag)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k + 1 < m && keys[k] == keys[k + 1]) flag[0] = 1;
 }
 
 // flags[0]: a column index out of [0, n); flags[1]: some row is not strictly ascending (unsorted or duplicate)

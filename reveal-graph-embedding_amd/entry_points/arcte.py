@@ -71,11 +71,11 @@ def main(argv=None):
                      epsilon=args.epsilon_threshold,
                      number_of_threads=number_of_tasks)
     features = spsp.csr_matrix(features)
+    features.sort_indices()
 
-    write_features(file_path=args.output_feature_path,
-                   features=features,
-                   separator=args.separator,
-                   node_to_id=node_to_id)
+    # every stored value is 1 except the diagonal of a node with a self-loop: I + ones = 2 (arcte.py:676-679)
+    loops = np.flatnonzero(adjacency_matrix.diagonal() != 0)
+    write_feature_triplets(args.output_feature_path, features.indptr, features.indices, loops, args.separator, node_to_id)
 
 
 if __name__ == "__main__":

@@ -64,3 +64,100 @@ def test_console_script_reproduces_the_reference_output_bytes(tmp_path):
     want = open(os.path.join(GOLDEN, "cli_features_expected.tsv")).read()
     assert sorted(got.splitlines()) == sorted(want.splitlines())
     assert got == want
+
+
+# ---- the native reader / writer (csrc/arcte_io.cpp) against a restatement of the reference's loops ------------------------
+
+def _reference_reader(path, separator, undirected):
+    """datarw.py:54-120 restated (test infrastructure): the loop the native reader replaces."""
+    id_to_node, row, col, data = {}, [], [], []
+    with open(path) as f:
+        for line in f:
+            words = line.strip().split(separator)
+            if words[0][0] == "#":
+                continue
+            s = id_to_node.setdefault(int(words[0]), len(id_to_node))
+            t = id_to_node.setdefault(int(words[1]), len(id_to_node))
+            w = float(words[2])
+            row.append(s); col.append(t); data.append(w)
+            if undirected and s != t:
+                row.append(t); col.append(s); data.append(w)
+    ids = [None] * len(id_to_node)
+    for k, v in id_to_node.items():
+        ids[v] = k
+    return len(id_to_node), np.array(row, np.int32), np.array(col, np.int32), np.array(data, np.float64), np.array(ids, np.int64)
+
+
+@pytest.mark.parametrize("separator", ["\t", ",", " ", "::"])
+@pytest.mark.parametrize("undirected", [False, True])
+def test_native_reader_equals_the_reference_loop(tmp_path, separator, undirected, monkeypatch):
+    from reveal_graph_embedding_amd.datautil.datarw import read_edge_triplets
+    rng = np.random.default_rng(7)
+    ids = rng.integers(-50, 10 ** 12, size=400)
+    lines = ["# comment line", "#another%sone" % separator]
+    for k in range(5000):
+        a, b = ids[rng.integers(0, ids.size)], ids[rng.integers(0, ids.size)]
+        w = ["1", "0.5", "2.25e-3", "-1.5", "3.", "1e5", "7.0" if separator == " " else " 7.0 "][k % 7]
+        lines.append("%s%d%s%d%s%s%s" % ("  " if k % 11 == 0 else "", a, separator, b, separator, w, "\r" if k % 13 == 0 else ""))
+        if k % 500 == 0:
+            lines.append("# mid-file comment")
+    lines.append("%d%s%d%s4.0%sextra field" % (ids[0], separator, ids[0], separator, separator))       # a self-loop, a fourth field
+    p = tmp_path / "edges.txt"
+    p.write_text("\n".join(lines))                                   # (no newline at the end of the file)
+    want = _reference_reader(str(p), separator, undirected)
+    for threads in ("1", "5"):
+        monkeypatch.setenv("ARCTE_HIP_IO_THREADS", threads)
+        got = read_edge_triplets(str(p), separator, undirected)
+        assert got[0] == want[0]
+        for g, w_ in zip(got[1:], want[1:]):
+            assert g.dtype == w_.dtype and np.array_equal(g, w_)
+
+
+def test_native_reader_reports_the_bad_line(tmp_path):
+    from reveal_graph_embedding_amd import _native
+    from reveal_graph_embedding_amd.datautil.datarw import read_edge_triplets
+    p = tmp_path / "bad.tsv"
+    p.write_text("1\t2\t1.0\n3\tx\t1.0\n")
+    with pytest.raises(_native.ArcteHipError) as e:
+        read_edge_triplets(str(p), "\t", False)
+    assert e.value.code == -1 and "line 2" in str(e.value)
+    p.write_text("1\t2\t1.0\n\n4\t5\t1\n")                          # the reference raises IndexError on an empty line
+    with pytest.raises(_native.ArcteHipError) as e:
+        read_edge_triplets(str(p), "\t", False)
+    assert "line 2" in str(e.value)
+    with pytest.raises(_native.ArcteHipError):
+        read_edge_triplets(str(tmp_path / "missing.tsv"), "\t", False)
+    p.write_text("")
+    n, row, col, val, ids = read_edge_triplets(str(p), "\t", True)
+    assert n == 0 and row.size == 0 and ids.size == 0
+
+
+def test_native_writer_equals_the_reference_loop(tmp_path, monkeypatch):
+    from reveal_graph_embedding_amd.datautil.datarw import write_feature_triplets
+    rng = np.random.default_rng(3)
+    n = 700
+    m = sparse.random(n, 2 * n, density=0.02, random_state=5, format="csr")
+    m.data[:] = 1.0
+    m = m + sparse.hstack([sparse.eye(n), sparse.csr_matrix((n, n))]).tocsr()          # every diagonal entry present
+    m = sparse.csr_matrix(m)
+    m.sort_indices()
+    doubled = np.sort(rng.choice(n, size=40, replace=False))
+    for i in doubled:
+        m[i, i] = 2.0
+    m.data[m.data > 2] = 1.0
+    for i in range(n):                                                                     # diagonal of the others is 1
+        if i not in set(doubled.tolist()):
+            m[i, i] = 1.0
+    m = sparse.csr_matrix(m)
+    m.sort_indices()
+    node_ids = rng.integers(-10, 10 ** 15, size=n)
+    ref = tmp_path / "ref.tsv"
+    write_features(str(ref), m, "\t", dict(enumerate(node_ids.tolist())))                  # the reference's per-entry loop
+    for threads in ("1", "6"):
+        monkeypatch.setenv("ARCTE_HIP_IO_THREADS", threads)
+        out = tmp_path / ("native%s.tsv" % threads)
+        write_feature_triplets(str(out), m.indptr, m.indices, doubled, "\t", node_ids)
+        assert out.read_bytes() == ref.read_bytes()
+    out = tmp_path / "dict.csv"
+    write_feature_triplets(str(out), m.indptr, m.indices, doubled, ",", dict(enumerate(node_ids.tolist())))
+    assert out.read_text() == ref.read_text().replace("\t", ",")

@@ -45,6 +45,17 @@ def test_float32_versus_float64_on_flickr_shaped_graph():
         c64b, r64b = ctx.fetch()
     assert np.array_equal(c64, c64b) and np.array_equal(r64, r64b)
 
+    # the float64 path on THIS shape against the oracle (the float32 numbers below are relative to it): 500 of the
+    # seeds, community sets and push counts exactly
+    from oracle import oracle
+    pick = np.linspace(0, seeds.size - 1, 500).astype(np.int64)
+    o_colptr, o_rows, _, o_nop, _ = oracle.worker(w, od, idg, seeds[pick], 0.1, 1e-5, threads=oracle.lib().oracle_max_threads(),
+                                                  want_stats=True)
+    assert np.array_equal(np.diff(c64)[pick], np.diff(o_colptr))
+    assert np.array_equal(nop64[pick], o_nop)
+    for j, k in enumerate(pick):
+        assert np.array_equal(np.sort(r64[c64[k]:c64[k + 1]]), o_rows[o_colptr[j]:o_colptr[j + 1]])
+
     inter = union = same = 0
     for k in range(seeds.size):
         a = set(r64[c64[k]:c64[k + 1]].tolist())
