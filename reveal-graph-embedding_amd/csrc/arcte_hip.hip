@@ -1019,6 +1019,13 @@ int arcte_hip_create(int device, int64_t n, int64_t nnz, const int64_t *indptr, 
     if (indptr[0] != 0 || indptr[n] != nnz) return fail(ARCTE_HIP_EINVAL, "indptr does not span [0, nnz]");
     for (int64_t i = 0; i < n; i++)
         if (indptr[i + 1] < indptr[i]) return fail(ARCTE_HIP_EINVAL, "indptr is not monotone");
+    {
+        // (one branch-free sweep: argument errors are reported before any device work; the check that needs memory and a
+        //  sort -- no column twice in a row -- runs on the device, validate_rows_on_device)
+        uint32_t bad = 0;
+        for (int64_t k = 0; k < nnz; k++) bad |= (uint32_t)(indices[k] < 0) | (uint32_t)((int64_t)indices[k] >= n);
+        if (bad) return fail(ARCTE_HIP_EINVAL, "column index out of range");
+    }
     arcte_hip_ctx *c = nullptr;
     int rc = ctx_begin(device, n, nnz, &c);
     if (rc) return rc;

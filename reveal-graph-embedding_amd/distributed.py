@@ -222,4 +222,4 @@ def arcte_and_centrality_distributed(adjacency_matrix, rho, epsilon, device=None
     features = sparse.hstack([base, local]).tocsr() if emitted.size else base
     if run_block is not None and getattr(run_block, "normalize", None) is not None:
         return run_block.normalize(features), centrality
-    return normalize_community_features(features), centrality
+    return normalize_community_features(features, device=device), centrality

@@ -1,7 +1,14 @@
 """Mirror of reveal_graph_embedding/embedding/arcte/cython_opt/arcte.pyx (reference lines 20-241): the reference's
 older single-process ARCTE driver -- raw epsilon, every node with out-edges a seed, columns numbered by a running
 counter, tf-idf + row normalised output -- and its centrality-collecting twin.  Propagation, the centrality
-accumulation, the assembly of the feature matrix and its normalisation all run on the GPU."""
+accumulation, the assembly of the feature matrix and its normalisation all run on the GPU.
+
+Restriction (round-2 advisor finding): the base block is I + W -- what the reference computes for a float64 CSR input,
+whose data array its cython transition (cython_opt/transition.pyx:19, no copy=True) normalises in place before
+`identity + adjacency_matrix` (arcte.pyx:227-228) is formed.  For an adjacency matrix of another dtype or format
+scipy's csr_matrix(..., dtype=float64) copies, the caller's matrix stays untouched and the reference's base block is
+I + A; that case is not reproduced here (the fixtures of tests/golden/make_golden_centrality.py are float64 CSR, the
+dtype arcte_and_centrality is called with in the reference's own pipeline)."""
 import numpy as np
 import scipy.sparse as sparse
 

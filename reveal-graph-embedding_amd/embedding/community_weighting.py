@@ -52,12 +52,12 @@ def community_weighting(X_train, X_test, community_weights):
     out = []
     for x in (X_train, X_test):
         f, own = _as_features(x)
-        f.community_weighting(community_weights)
-        if own:
-            out.append(f.to_scipy())
-            f.close()
-        else:
-            out.append(f)
+        try:
+            f.community_weighting(community_weights)
+            out.append(f.to_scipy() if own else f)
+        finally:
+            if own:
+                f.close()
     return out[0], out[1]
 
 
