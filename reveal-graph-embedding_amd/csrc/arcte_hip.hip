@@ -142,6 +142,34 @@ void release_cached(DevBuf<T> &b, int device)
     b.release();
 }
 
+// The slot memory of the line state: a hipMalloc buffer that is parked in the process-wide cache between contexts.
+// (Composing it from physical chunks mapped at chunk-aligned virtual addresses -- hipMemCreate / hipMemAddressReserve /
+// hipMemMap -- was tried in round 3 to take the chance out of how virtual and physical addresses are aligned to each
+// other: with 64 MB and 1 GB chunks the kernel's duration stayed on the same two levels, with 256 MB chunks three runs
+// out of three returned WRONG results -- a node's value read back as untouched -- so that path is not in the library.)
+struct SlotMem {
+    char *p = nullptr;
+    size_t size = 0;
+    DevBuf<char> plain;
+    size_t bytes() const { return size; }
+    hipError_t alloc(size_t bytes, int device)
+    {
+        release(device);
+        size = bytes;
+        if (bytes == 0) return hipSuccess;
+        hipError_t r = alloc_cached(plain, bytes, device);
+        p = plain.p;
+        return r;
+    }
+    void release(int device)
+    {
+        release_cached(plain, device);
+        plain.release();
+        p = nullptr;
+        size = 0;
+    }
+};
+
 int32_t max_pushes_limit()
 {
     if (const char *env = getenv("ARCTE_HIP_MAX_PUSHES")) {
@@ -226,12 +254,11 @@ struct arcte_hip_ctx {
     DevBuf<double> in_degree_r;
     int64_t l_slots = 0;
     uint32_t l_M = 0, l_Mshift = 0, l_MB = 0, l_MBshift = 0, l_qcap = 0, l_pcap = 0, l_scap = 0;
-    DevBuf<uint32_t> l_gbm;       // [slots][MB / 32] touched-line bits of region B
     int l_waves_per_cu = 0;
-    DevBuf<double> l_vals;
-    DevBuf<double2> l_ps;
-    DevBuf<int32_t> l_sup;
-    DevBuf<QEntry> l_queue;
+    // ONE block per slot for what a wavefront touches all the time, [region A values | ring | candidate list | pushed
+    // state | region B bits], and one for region B's values; both sizes are powers of two (lines_layout)
+    SlotMem l_block, l_blockb;
+    size_t l_block_bytes = 0, l_blockb_bytes = 0, l_off_queue = 0, l_off_sup = 0, l_off_ps = 0, l_off_gbm = 0, l_off_b = 0;
     DevBuf<unsigned long long> l_stats;
     int64_t line_stats[4] = {0, 0, 0, 0};   // last run: LDS updates, blind line writes, read-modify-writes, updates of pushed nodes
     // per-run
@@ -276,7 +303,7 @@ struct arcte_hip_ctx {
                nop_d.bytes() + eps_d.bytes() + out_off.bytes() + dst_off.bytes() + raw.bytes() + rows_final.bytes() +
                edge_rank.bytes() + node_rank.bytes() + rowspan.bytes() + in_degree_r.bytes() + slot_bytes_lines();
     }
-    size_t slot_bytes_lines() const { return l_vals.bytes() + l_ps.bytes() + l_sup.bytes() + l_queue.bytes() + l_gbm.bytes(); }
+    size_t slot_bytes_lines() const { return l_block.bytes() + l_blockb.bytes(); }
     size_t slot_bytes_dense() const { return state.bytes() + sup.bytes() + queue.bytes() + hqueue.bytes() + warm.bytes(); }
 };
 
@@ -399,20 +426,53 @@ uint32_t lines_hot_values(const arcte_hip_ctx *c)
     return (uint32_t)k;
 }
 
+// The layout of a slot's memory.  A wavefront's every access is a random one into its own slot, so the cost of address
+// translation is decided by how a slot's OFTEN touched bytes sit in the address space -- measured, ms per 81 434 seeds of
+// the 1M/50M graph over fresh contexts of one process (profiles/r03/context_lottery_*.txt):
+//   five arrays, one per kind (values, ring, candidates, pushed state, bits), slot after slot in each:  77 ... 96
+//   [line][slot]: line l of every slot side by side, a slot spread over ALL pages:                      96 ... 100
+//   one block per slot of a whole number of 2 MB pages (14 MB):                                         76 / 86 / 98
+//   one block per slot whose size is a power of two (16 MB), i.e. every slot aligned to its size:       81.6 (11 of 12)
+// Translations are cached for aligned power-of-two ranges; a slot that starts at an odd multiple of 2 MB is served by
+// 2 MB ranges, one that starts at a multiple of its size by one range.  So: the often touched parts -- region A's values,
+// the ring, the candidate list, the pushed-state array, region B's touched-bits -- form ONE block of power-of-two size
+// (4 MB with the default capacities), and region B's values, touched by a few per cent of the updates, another.
+struct LinesLayout { size_t off_queue, off_sup, off_ps, off_gbm, off_b, block, blockb; };
+LinesLayout lines_layout(const arcte_hip_ctx *c, uint32_t qcap, uint32_t pcap, uint32_t scap)
+{
+    auto up = [](size_t x, size_t a) { return (x + a - 1) / a * a; };
+    LinesLayout y;
+    size_t o = ((size_t)c->l_M << 3) * sizeof(double);
+    y.off_queue = o; o += up((size_t)qcap * sizeof(QEntry), 256);
+    y.off_sup = o;   o += up((size_t)scap * sizeof(int32_t), 256);
+    y.off_ps = o;    o += up((size_t)pcap * sizeof(double2), 256);
+    y.off_gbm = o;   o += up((size_t)(c->l_MB >> 5) * sizeof(uint32_t), 256);
+    const bool pow2 = env_int("ARCTE_HIP_SLOT_POW2", 1) != 0;         // 0: whole 2 MB pages only (A/B)
+    const bool split = env_int("ARCTE_HIP_SLOT_SPLIT", 1) != 0;       // 1: region B's values in an allocation of their own (A/B)
+    const size_t bytes_b = ((size_t)c->l_MB << 3) * sizeof(double);   // (MB is a power of two)
+    y.off_b = o;
+    if (!split) o += bytes_b;
+    auto pow2_size = [&](size_t x) { size_t p = 4096; while (p < x) p <<= 1; return p; };
+    y.block = pow2 ? pow2_size(o) : up(o, (size_t)2 << 20);
+    y.blockb = split ? bytes_b : 0;
+    return y;
+}
+
 size_t lines_bytes_per_slot(const arcte_hip_ctx *c, uint32_t qcap, uint32_t pcap, uint32_t scap)
 {
-    return (((size_t)c->l_M + c->l_MB) << 3) * sizeof(double) + c->l_MB / 8 + (size_t)qcap * sizeof(QEntry) + (size_t)pcap * sizeof(double2) +
-           (size_t)scap * sizeof(int32_t);
+    const LinesLayout y = lines_layout(c, qcap, pcap, scap);
+    return y.block + y.blockb;
 }
 
 int alloc_lines(arcte_hip_ctx *c, int64_t slots, uint32_t qcap, uint32_t pcap, uint32_t scap)
 {
-    // (nothing is cleared: a value is only ever read after the bitmap in LDS said its line was written by this seed)
-    HIP_TRY(alloc_cached(c->l_vals, (size_t)slots * (((size_t)c->l_M + c->l_MB) << 3), c->device));
-    HIP_TRY(alloc_cached(c->l_gbm, (size_t)slots * (c->l_MB >> 5), c->device));
-    HIP_TRY(alloc_cached(c->l_queue, (size_t)slots * qcap, c->device));
-    HIP_TRY(alloc_cached(c->l_ps, (size_t)slots * pcap, c->device));
-    HIP_TRY(alloc_cached(c->l_sup, (size_t)slots * scap, c->device));
+    // (nothing is cleared: a value is only ever read after a bitmap said its line was written by this seed)
+    const LinesLayout y = lines_layout(c, qcap, pcap, scap);
+    HIP_TRY(c->l_block.alloc((size_t)slots * y.block, c->device));
+    HIP_TRY(c->l_blockb.alloc((size_t)slots * y.blockb, c->device));
+    c->l_block_bytes = y.block;
+    c->l_blockb_bytes = y.blockb;
+    c->l_off_queue = y.off_queue; c->l_off_sup = y.off_sup; c->l_off_ps = y.off_ps; c->l_off_gbm = y.off_gbm; c->l_off_b = y.off_b;
     if (!c->l_stats.p) HIP_TRY(c->l_stats.alloc(4));
     c->l_slots = slots;
     c->l_qcap = qcap;
@@ -444,8 +504,8 @@ int grow_lines(arcte_hip_ctx *c, bool queue_over, bool pushed_over, bool sup_ove
     free_b += c->slot_bytes_lines() + cached_bytes_on(c->device);
     int64_t slots = c->l_slots;
     while (slots > 1 && (size_t)slots * lines_bytes_per_slot(c, qcap, pcap, scap) > free_b / 4 * 3) slots = (slots + 1) / 2;
-    release_cached(c->l_vals, c->device); release_cached(c->l_queue, c->device); release_cached(c->l_ps, c->device); release_cached(c->l_sup, c->device);
-    release_cached(c->l_gbm, c->device);
+    c->l_block.release(c->device);
+    c->l_blockb.release(c->device);
     return alloc_lines(c, slots, qcap, pcap, scap);
 }
 
@@ -480,19 +540,34 @@ int launch_lines(arcte_hip_ctx *c, PushParams P, int64_t nwork, int variant, int
     L.ranked_ids = c->ranked_ids.p;
     L.rowspan = c->rowspan.p;
     L.in_degree_r = c->in_degree_r.p;
-    L.vals = c->l_vals.p;
-    L.ps = c->l_ps.p;
-    L.sup = c->l_sup.p;
+    // a slot's parts (the kernel addresses region A's and region B's values through ONE index: line * 8 + place, region
+    // B's lines continuing region A's)
+    char *block = c->l_block.p;
+    L.vals = reinterpret_cast<double *>(block);
+    if (c->l_blockb_bytes) {          // region B's values in an allocation of their own
+        L.vals_b = reinterpret_cast<double *>(c->l_blockb.p) - ((int64_t)c->l_M << 3);      // indexed from region A's first line
+        L.valsb_stride = (int64_t)(c->l_blockb_bytes / sizeof(double));
+    } else {
+        L.vals_b = reinterpret_cast<double *>(block + c->l_off_b) - ((int64_t)c->l_M << 3);
+        L.valsb_stride = (int64_t)(c->l_block_bytes / sizeof(double));
+    }
+    L.ps = reinterpret_cast<double2 *>(block + c->l_off_ps);
+    L.sup = reinterpret_cast<int32_t *>(block + c->l_off_sup);
+    L.gbm = reinterpret_cast<uint32_t *>(block + c->l_off_gbm);
     L.M = c->l_M;
     L.Mshift = c->l_Mshift;
     L.MB = c->l_MB;
     L.MBshift = c->l_MBshift;
-    L.gbm = c->l_gbm.p;
+    L.vals_stride = (int64_t)(c->l_block_bytes / sizeof(double));
+    L.ps_stride = (int64_t)(c->l_block_bytes / sizeof(double2));
+    L.sup_stride = (int64_t)(c->l_block_bytes / sizeof(int32_t));
+    L.q_stride = (int64_t)(c->l_block_bytes / sizeof(QEntry));
+    L.gbm_stride = (int64_t)(c->l_block_bytes / sizeof(uint32_t));
     L.pcap = c->l_pcap;
     L.scap = c->l_scap;
     L.K = lines_hot_values(c);
     L.lstats = c->l_stats.p;
-    P.queue = c->l_queue.p;
+    P.queue = reinterpret_cast<QEntry *>(c->l_block.p + c->l_off_queue);
     P.qcap = c->l_qcap;
     const size_t lds = (size_t)L.K * sizeof(double) + c->l_M / 8;
     const int blocks = (int)std::min<int64_t>(c->l_slots, std::max<int64_t>(nwork, 1));
@@ -788,7 +863,7 @@ int setup_lines(arcte_hip_ctx *c, uint32_t M)
         while ((1u << c->l_MBshift) < c->l_MB) c->l_MBshift++;
     }
     // (a seed of the 1M/50M graph enqueues 210 nodes; the ring grows by four and the seed is re-run when it overflows)
-    uint32_t qcap = c->want_queue > 0 ? next_pow2((uint64_t)c->want_queue) : std::min<uint32_t>(default_queue_capacity(n), 1u << 16);
+    uint32_t qcap = c->want_queue > 0 ? next_pow2((uint64_t)c->want_queue) : std::min<uint32_t>(default_queue_capacity(n), 1u << 15);
     if (qcap < (uint32_t)WAVE) qcap = WAVE;
     const uint32_t node_cap = next_pow2((uint64_t)n);
     // a seed of the 1M/50M graph pushes 190 distinct nodes (p99 600, tools/line_study.py) and lists a few thousand
@@ -1238,9 +1313,9 @@ int arcte_hip_destroy(arcte_hip_ctx *c)
     release_cached(c->contrib_key, c->device); release_cached(c->contrib_val, c->device);
     release_cached(c->contrib_key_sorted, c->device); release_cached(c->contrib_val_sorted, c->device);
     c->contrib_temp.release(); c->run_first.release(); c->run_last.release();
-    release_cached(c->l_vals, c->device); release_cached(c->l_queue, c->device); release_cached(c->l_ps, c->device); release_cached(c->l_sup, c->device);
-    release_cached(c->l_gbm, c->device);
-    c->l_vals.release(); c->l_queue.release(); c->l_ps.release(); c->l_sup.release(); c->l_stats.release(); c->l_gbm.release();
+    c->l_block.release(c->device);
+    c->l_blockb.release(c->device);
+    c->l_stats.release();
     c->edge_rank.release(); c->node_rank.release(); c->rowspan.release(); c->in_degree_r.release();
     c->state.release(); c->slot_epoch.release(); c->warm.release(); c->contrib_key.release(); c->contrib_val.release(); c->centrality.release(); c->ranked_ids.release(); c->node_hot.release(); c->edge_hot.release(); c->edge_in_degree.release(); c->data_f.release(); c->in_degree_f.release(); c->edge_in_degree_f.release(); c->queue.release(); c->hqueue.release(); c->prof.release(); c->sup.release();
     c->seeds_d.release(); c->work_pos.release(); c->out_cnt.release(); c->status.release(); c->nop_d.release();

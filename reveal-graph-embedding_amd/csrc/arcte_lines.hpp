@@ -39,12 +39,18 @@ struct LineParams {
     const int32_t *ranked_ids;    // [n] rank -> node
     const int64_t *rowspan;       // [2n] by rank: first and one-past-last edge of the node's row
     const double *in_degree_r;    // [n] by rank
-    double *vals;                 // [slots][8 (M + MB)]
+    double *vals;                 // region A: 8 M values per slot
+    double *vals_b;               // region B: 8 MB values per slot, addressed with region A's index space (lines M ..)
     double2 *ps;                  // [slots][pcap]
     int32_t *sup;                 // [slots][scap] candidate list (ranks)
     uint32_t M, Mshift;           // region A: lines per slot whose touched-bits are in LDS (power of two), log2; ranks < 8 M
     uint32_t MB, MBshift;         // region B (TAIL): lines for the ranks >= 8 M, touched-bits in gbm (0: every rank is in A)
     uint32_t *gbm;                // [slots][MB / 32]
+    // distance between two slots' parts of the arrays above, in elements of each: a slot's often touched parts (region A,
+    // ring, candidates, pushed state, region B's bits) lie in ONE block whose size is a power of two, region B's values in
+    // another (arcte_hip.hip: lines_layout)
+    int64_t vals_stride, valsb_stride, ps_stride, sup_stride, q_stride, gbm_stride;
+
     uint32_t pcap, scap;
     uint32_t K;                   // values of the LDS level
     unsigned long long *lstats;   // [0] LDS updates [1] blind line writes [2] read-modify-writes [3] updates of pushed nodes
@@ -65,7 +71,7 @@ template <int C> __device__ __forceinline__ uint32_t quad_bcast(uint32_t v)
 // whole, contiguous 64-byte lines and the memory pipeline sees ONE full-line request per line -- 41.7 G mixed updates/s
 // against 22.3 when each lane writes its own line with four 16-byte stores (tools/line_wall.hip, shapes 1 / 0).
 template <int C>
-__device__ __forceinline__ void blind_round(double *vals, int lane, uint32_t own, uint32_t index, uint32_t plo, uint32_t phi)
+__device__ __forceinline__ void blind_round(double *vals, double *vals_b, uint32_t RA, int lane, uint32_t own, uint32_t index, uint32_t plo, uint32_t phi)
 {
     const uint32_t o = quad_bcast<C>(own);
     const uint32_t ix = quad_bcast<C>(index);          // value index of the owner's node: line = ix / 8, place = ix % 8
@@ -73,7 +79,7 @@ __device__ __forceinline__ void blind_round(double *vals, int lane, uint32_t own
     if (o) {
         const uint32_t ql = (uint32_t)lane & 3u, s_ = ix & 7u;
         const bool hit = ql == (s_ >> 1);
-        reinterpret_cast<double2 *>(vals + (size_t)(ix & ~7u))[ql] = make_double2((hit && !(s_ & 1)) ? p : 0.0, (hit && (s_ & 1)) ? p : 0.0);
+        reinterpret_cast<double2 *>((ix < RA ? vals : vals_b) + (size_t)(ix & ~7u))[ql] = make_double2((hit && !(s_ & 1)) ? p : 0.0, (hit && (s_ & 1)) ? p : 0.0);
     }
 }
 
@@ -108,11 +114,12 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(WPE))) voi
     uint32_t *bm = reinterpret_cast<uint32_t *>(hot + K);
     const uint32_t RA = L.M << 3;                    // first rank of region B
     const uint32_t MBmask = L.MB - 1, MBshift = L.MBshift;
-    double *__restrict__ vals = L.vals + slot * (((int64_t)L.M + (int64_t)L.MB) << 3);
-    uint32_t *__restrict__ gbm = L.gbm + slot * (int64_t)(L.MB >> 5);
-    double2 *__restrict__ ps = L.ps + slot * (int64_t)L.pcap;
-    int32_t *__restrict__ sup = L.sup + slot * (int64_t)L.scap;
-    QEntry *__restrict__ q = P.queue + slot * (int64_t)P.qcap;
+    double *__restrict__ vals = L.vals + slot * L.vals_stride;
+    double *__restrict__ vals_b = L.vals_b + slot * L.valsb_stride;
+    uint32_t *__restrict__ gbm = L.gbm + slot * L.gbm_stride;
+    double2 *__restrict__ ps = L.ps + slot * L.ps_stride;
+    int32_t *__restrict__ sup = L.sup + slot * L.sup_stride;
+    QEntry *__restrict__ q = P.queue + slot * L.q_stride;
     const uint32_t qmask = P.qcap - 1;
     const double omr = P.one_minus_rho;
 
@@ -127,6 +134,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(WPE))) voi
         if (in_b(rk)) { const uint32_t rp = rk - RA; return RA + (((rp & MBmask) << 3) | (rp >> MBshift)); }
         return ((rk & Mmask) << 3) | (rk >> Mshift);
     };
+    auto val_at = [&](uint32_t ix) -> double * { return (ix < RA ? vals : vals_b) + ix; };     // ix = line * 8 + place; region B's lines follow A's
     auto line_touched = [&](uint32_t rk) -> bool {
         if (in_b(rk)) { const uint32_t ln = (rk - RA) & MBmask; return (gbm[ln >> 5] >> (ln & 31)) & 1u; }
         const uint32_t ln = rk & Mmask;
@@ -135,10 +143,10 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(WPE))) voi
     // the value that stands in a node's place: on chip, in its line, or 0 when the line has not been touched
     auto raw_value = [&](uint32_t rk) -> double {
         if (rk < K) return hot[rk];
-        return line_touched(rk) ? vals[value_index(rk)] : 0.0;
+        return line_touched(rk) ? *val_at(value_index(rk)) : 0.0;
     };
     // a node that HAS a value (it was deposited to): no look at the bitmap
-    auto live_value = [&](uint32_t rk) -> double { return rk < K ? hot[rk] : vals[value_index(rk)]; };
+    auto live_value = [&](uint32_t rk) -> double { return rk < K ? hot[rk] : *val_at(value_index(rk)); };
 
     unsigned long long drawn = 0;
     unsigned long long c_lds = 0, c_blind = 0, c_rmw = 0, c_moved = 0;
@@ -239,10 +247,10 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(WPE))) voi
                         const double p = c * wt;
                         const uint32_t own = owner ? 1u : 0u;
                         const uint32_t plo = (uint32_t)__double2loint(p), phi = (uint32_t)__double2hiint(p);
-                        blind_round<0>(vals, lane, own, index, plo, phi);
-                        blind_round<1>(vals, lane, own, index, plo, phi);
-                        blind_round<2>(vals, lane, own, index, plo, phi);
-                        blind_round<3>(vals, lane, own, index, plo, phi);
+                        blind_round<0>(vals, vals_b, RA, lane, own, index, plo, phi);
+                        blind_round<1>(vals, vals_b, RA, lane, own, index, plo, phi);
+                        blind_round<2>(vals, vals_b, RA, lane, own, index, plo, phi);
+                        blind_round<3>(vals, vals_b, RA, lane, own, index, plo, phi);
                     }
                     // (every lane issues the load: the others at a cached address of the slot)
                     ld_index[t] = (line_lvl && !owner) ? index : 0u;
@@ -253,7 +261,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(WPE))) voi
                 //  first touches and on-chip nodes only -- there is nothing to wait for: a wave-uniform branch)
                 if (skip_if_none && __ballot(any_load) == 0) return;
 #pragma unroll
-                for (int t = 0; t < LT; t++) E.x[t] = vals[ld_index[t]];
+                for (int t = 0; t < LT; t++) E.x[t] = *val_at(ld_index[t]);
             };
             // stage 3: the value in the node's place; a pushed node's NaN points into PS
             // (skip_if_none: a row of one step has nothing to overlap the load with, so it is only issued when some
@@ -292,7 +300,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(WPE))) voi
                     if (act) {
                         if (mv) ps[moved_index(x)] = make_double2(r_new, s_new);
                         else if (rk < K) hot[rk] = r_new;
-                        else if (!E.owner[t]) vals[value_index(rk)] = r_new;
+                        else if (!E.owner[t]) *val_at(value_index(rk)) = r_new;
                     }
                     s_moved += __popcll(__ballot(mv));
                     s_lds += __popcll(__ballot(act && !mv && rk < K));
@@ -396,7 +404,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(WPE))) voi
                 if (lane == 0) {
                     ps[ju] = make_double2(r_self, s_self);
                     if (u < K) hot[u] = moved_to((uint32_t)ju);
-                    else vals[value_index(u)] = moved_to((uint32_t)ju);
+                    else *val_at(value_index(u)) = moved_to((uint32_t)ju);
                 }
                 if (VAR != 0) {
                     const bool grew = s_self != 0.0;
@@ -445,7 +453,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(WPE))) voi
                 if (in_b(sr)) { const uint32_t ln = (sr - RA) & MBmask; gbm[ln >> 5] |= 1u << (ln & 31); }
                 else { const uint32_t ln = sr & Mmask; bm[ln >> 5] |= 1u << (ln & 31); }
                 const uint32_t ix = value_index(sr), sl = ix & 7u;
-                double2 *line = reinterpret_cast<double2 *>(vals + (size_t)(ix & ~7u));
+                double2 *line = reinterpret_cast<double2 *>(val_at(ix & ~7u));
                 const double m0 = moved_to(0);
                 for (uint32_t ch = 0; ch < 4; ch++)
                     line[ch] = (ch == (sl >> 1)) ? ((sl & 1) ? make_double2(0.0, m0) : make_double2(m0, 0.0)) : make_double2(0.0, 0.0);
