@@ -470,6 +470,11 @@ int alloc_lines(arcte_hip_ctx *c, int64_t slots, uint32_t qcap, uint32_t pcap, u
     const LinesLayout y = lines_layout(c, qcap, pcap, scap);
     HIP_TRY(c->l_block.alloc((size_t)slots * y.block, c->device));
     HIP_TRY(c->l_blockb.alloc((size_t)slots * y.blockb, c->device));
+    if (const int poison = env_int("ARCTE_HIP_POISON", -1); poison >= 0) {
+        // test hook: the slot memory starts as garbage of the caller's choice -- nothing may depend on what it held
+        HIP_TRY(hipMemsetAsync(c->l_block.p, poison, c->l_block.bytes(), c->stream));
+        if (c->l_blockb.bytes()) HIP_TRY(hipMemsetAsync(c->l_blockb.p, poison, c->l_blockb.bytes(), c->stream));
+    }
     c->l_block_bytes = y.block;
     c->l_blockb_bytes = y.blockb;
     c->l_off_queue = y.off_queue; c->l_off_sup = y.off_sup; c->l_off_ps = y.off_ps; c->l_off_gbm = y.off_gbm; c->l_off_b = y.off_b;

@@ -111,3 +111,17 @@ def test_consecutive_contexts_get_the_same_slots():
             ctx.run_seeds(g["all_seeds"][:50], g["rho"], g["epsilon"])
             slots.append(ctx.info()["slots"])
     assert slots[0] == slots[1] == slots[2]
+
+
+@pytest.mark.parametrize("poison", [255, 165])
+def test_slot_memory_content_is_irrelevant(poison, monkeypatch):
+    """Nothing is cleared between seeds or contexts: a value is only read after a bitmap said its line was written by
+    this seed.  So the slot memory may start as any garbage (ARCTE_HIP_POISON fills it with a byte: 0xFF = NaNs)."""
+    g = load_golden("rmat2000")
+    o_colptr, o_rows, _, o_nop, _ = oracle.worker(g["w"], g["out_degree"], g["in_degree"], g["all_seeds"], g["rho"], g["epsilon"],
+                                                  want_stats=True)
+    monkeypatch.setenv("ARCTE_HIP_POISON", str(poison))
+    for hot, lines_lds in ((0, 64), (16, 64), (-1, None)):
+        colptr, rows, nop, st, info = run(g, hot, lines_lds, oracle.ARCTE, monkeypatch)
+        assert np.array_equal(colptr, o_colptr) and np.array_equal(nop, o_nop)
+        assert np.array_equal(sorted_rows(colptr, rows), o_rows)
