@@ -190,6 +190,7 @@ def main():
     shard = shard_seeds(seeds, args.shards, rank)
     info = ctx.info()
     state = ctx.state_info()
+    placement_kept, placement_rates = ctx.placement_info()
     log("[bench] rank %d: n=%d nnz=%d seeds=%d shard=%d slots=%d device_bytes=%.1f GB" % (
         rank, args.nodes, nnz, seeds.size, shard.size, info["slots"], info["device_bytes"] / 1e9))
 
@@ -371,6 +372,9 @@ def main():
                                                 "bitmap_lds_bytes", "lds_bytes_per_wave", "lines_region_b")},
                 "kernel_source_id": kernel_source_id(),
                 "placement_tries": len(placement_ms), "placement_calibration_ms": [round(x, 2) for x in placement_ms],
+                # the library's own draw of the slot memory at context creation (every caller gets it): G updates/s of the
+                # probe on each candidate allocation, and which one was kept
+                "slot_memory_probe_gups": [round(x, 2) for x in placement_rates], "slot_memory_kept": placement_kept,
                 "emitted_rows_rank0": int(total_rows), "emitted_rows_all_ranks": emitted_all, "merged_sha256": merged_sha,
                 "gathered_rows_rank0": int(gathered_rows),
                 "sub_launches": nsub, "gather_ms_per_step_rank0": gather_ms / max(args.steps, 1),

@@ -361,6 +361,13 @@ int arcte_hip_info(arcte_hip_ctx *ctx, int64_t info[10]);
  * [10] read-modify-writes of a line, [11] updates of pushed nodes. */
 int arcte_hip_state_info(arcte_hip_ctx *ctx, int64_t info[12]);
 
+/* The draws of the slot memory's placement made when the context was created (no counterpart in the reference): the
+ * propagation kernel's speed depends on how its per-seed state is laid over the physical memory, which hipMalloc leaves
+ * to chance, so a context large enough to care allocates up to ARCTE_HIP_PLACEMENT_TRIES (8) candidates, measures a few
+ * milliseconds of random read-modify-writes on each, stops when one is 10 % faster than another and keeps the fastest.  *drawn = candidates measured (0: no draw),
+ * *kept = index of the one in use, rates[i] = G updates/s of candidate i (up to `capacity` of them). */
+int arcte_hip_placement_info(arcte_hip_ctx *ctx, int *kept, double *rates, int capacity, int *drawn);
+
 #ifdef __cplusplus
 }
 #endif

@@ -65,6 +65,7 @@ SIGNATURES = {
     "arcte_hip_write_feature_triplets": (C.c_int, [C.c_char_p, C.c_int64, _i64p, C.c_void_p, _i64p, _i64p, C.c_int64, C.c_char_p]),
     "arcte_hip_info": (C.c_int, [C.c_void_p, _i64p]),
     "arcte_hip_state_info": (C.c_int, [C.c_void_p, _i64p]),
+    "arcte_hip_placement_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), _f64p, C.c_int, C.POINTER(C.c_int)]),
     "arcte_hip_launch_occupancy": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "arcte_hip_features_from_result": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
     "arcte_hip_features_upload": (C.c_int, [C.c_int, C.c_int64, C.c_int64, C.c_int64, _i64p, _i32p, _f64p, C.POINTER(C.c_void_p)]),
@@ -414,6 +415,13 @@ class Context:
                     slot_bytes=int(i[4]), bitmap_lds_bytes=int(i[5]), lds_bytes_per_wave=int(i[6]), lines_region_b=int(i[7]),
                     lds_updates=int(i[8]), blind_line_writes=int(i[9]), line_read_modify_writes=int(i[10]),
                     pushed_node_updates=int(i[11]))
+
+    def placement_info(self):
+        """The candidate allocations of the slot memory probed at creation: (index kept, [G updates/s per candidate])."""
+        kept, drawn = C.c_int(-1), C.c_int(0)
+        rates = np.zeros(8, dtype=np.float64)
+        _check(lib().arcte_hip_placement_info(self._h, C.byref(kept), rates, rates.size, C.byref(drawn)))
+        return kept.value, [float(x) for x in rates[:drawn.value]]
 
     def launch_occupancy(self):
         """Workgroups of the propagation kernel per CU according to the runtime's occupancy query (diagnostic)."""

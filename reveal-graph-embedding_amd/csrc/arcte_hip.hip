@@ -58,6 +58,10 @@ int fail(int code, const std::string &msg)
             return fail(ARCTE_HIP_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_));         \
     } while (0)
 
+// (slot-memory candidates that lost their draw are parked, not freed: see draw_slot_memory; they are returned when an
+//  allocation fails)
+bool free_parked_buffers();
+
 template <typename T>
 struct DevBuf {
     T *p = nullptr;
@@ -67,6 +71,10 @@ struct DevBuf {
         release();
         count = c;
         hipError_t e = hipMalloc((void **)&p, std::max<size_t>(c, 1) * sizeof(T));
+        if (e != hipSuccess && free_parked_buffers()) {
+            (void)hipGetLastError();
+            e = hipMalloc((void **)&p, std::max<size_t>(c, 1) * sizeof(T));
+        }
         if (e == hipSuccess) capacity = std::max<size_t>(c, 1);
         return e;
     }
@@ -100,6 +108,25 @@ struct DevBuf {
 struct BigCacheEntry { int device; void *p; size_t bytes; };
 std::mutex g_big_mutex;
 std::vector<BigCacheEntry> g_big_cache;
+// Slot-memory candidates that lost a placement draw (draw_slot_memory): kept allocated, so that the allocator cannot hand
+// the same slow memory out again and no deferred hipFree has to be paid for by the next hipMalloc (2.2 s measured);
+// returned by arcte_hip_trim() and whenever an allocation fails.  g_best_probe: the fastest probe rate seen per
+// (device, size) in this process -- a candidate that reaches it is taken at once.
+std::vector<BigCacheEntry> g_parked;
+struct BestProbe { int device; size_t bytes; double rate; };
+std::vector<BestProbe> g_best_probe;
+
+bool free_parked_buffers()
+{
+    std::lock_guard<std::mutex> lock(g_big_mutex);
+    const bool any = !g_parked.empty();
+    for (auto &e : g_parked) {
+        (void)hipSetDevice(e.device);
+        (void)hipFree(e.p);
+    }
+    g_parked.clear();
+    return any;
+}
 constexpr size_t BIG_BUFFER = (size_t)256 << 20;
 
 template <typename T>
@@ -261,6 +288,8 @@ struct arcte_hip_ctx {
     size_t l_block_bytes = 0, l_blockb_bytes = 0, l_off_queue = 0, l_off_sup = 0, l_off_ps = 0, l_off_gbm = 0, l_off_b = 0;
     DevBuf<unsigned long long> l_stats;
     int64_t line_stats[4] = {0, 0, 0, 0};   // last run: LDS updates, blind line writes, read-modify-writes, updates of pushed nodes
+    std::vector<double> placement_probe;    // G updates/s of every candidate allocation of the slot memory, in draw order
+    int placement_kept = -1;
     // per-run
     int64_t run_nseeds = -1;
     DevBuf<int32_t> seeds_d, work_pos, out_cnt, status, nop_d;
@@ -400,6 +429,8 @@ size_t cached_bytes_on(int device)
     size_t b = 0;
     for (const auto &e : g_big_cache)
         if (e.device == device) b += e.bytes;
+    for (const auto &e : g_parked)          // (returned as soon as an allocation fails)
+        if (e.device == device) b += e.bytes;
     return b;
 }
 
@@ -464,11 +495,106 @@ size_t lines_bytes_per_slot(const arcte_hip_ctx *c, uint32_t qcap, uint32_t pcap
     return y.block + y.blockb;
 }
 
+// The slot memory's placement decides the propagation kernel's speed (two main levels 23 % apart),
+// and hipMalloc leaves it to chance.  So a context that is large enough to care draws up to ARCTE_HIP_PLACEMENT_TRIES (3)
+// candidate allocations -- alive at the same time, so that they are different memory --, runs k_probe_slots on each (a
+// few milliseconds of the kernel's own access pattern) and keeps the fastest; the others are freed.  The probe sees two
+// classes of memory (24 and 20 G updates/s on the 1M/50M graph's slots, and the push kernel runs 646 or 777 ms on them):
+// the draw stops as soon as it holds a candidate 10 % faster than another one.  Every caller gets this -- arcte(), the
+// console script, bench.py alike.  A draw is skipped when the device has no room for another candidate.
+int draw_slot_memory(arcte_hip_ctx *c, size_t slots, size_t block)
+{
+    const size_t bytes = slots * block;
+    c->placement_probe.clear();
+    c->placement_kept = -1;
+    int tries = std::max(1, std::min(16, env_int("ARCTE_HIP_PLACEMENT_TRIES", 8)));
+    // (a draw costs ~0.1 s per candidate: only for graphs whose runs are long enough to repay it)
+    if (bytes < ((size_t)1 << 30) || slots < 256 || c->n < (int64_t)env_int("ARCTE_HIP_PLACEMENT_MIN_NODES", 262144)) tries = 1;
+    if (tries == 1) {
+        HIP_TRY(c->l_block.alloc(bytes, c->device));
+        return 0;
+    }
+    std::vector<SlotMem> cand((size_t)tries);
+    DevBuf<unsigned long long> sink;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int best = -1;
+    double known_best = 0.0;
+    {
+        std::lock_guard<std::mutex> lock(g_big_mutex);
+        for (const auto &b : g_best_probe)
+            if (b.device == c->device && b.bytes == bytes) known_best = b.rate;
+    }
+    int rc = [&]() -> int {
+        HIP_TRY(sink.alloc(1));
+        HIP_TRY(hipEventCreate(&e0));
+        HIP_TRY(hipEventCreate(&e1));
+        const uint32_t span = (uint32_t)(std::min<size_t>(block, ((size_t)c->l_M << 3) * sizeof(double)) / sizeof(double));
+        for (int t = 0; t < tries; t++) {
+            if (t > 0) {
+                size_t free_b = 0, total_b = 0;
+                HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+                if (free_b + cached_bytes_on(c->device) < bytes + bytes / 2 + ((size_t)24 << 30)) break;      // no room for another candidate
+            }
+            const auto ta = std::chrono::steady_clock::now();
+            if (cand[(size_t)t].alloc(bytes, c->device) != hipSuccess) { (void)hipGetLastError(); cand[(size_t)t].release(c->device); break; }
+            if (env_int("ARCTE_HIP_VERBOSE", 0))
+                fprintf(stderr, "[arcte_hip] slot memory candidate %d: %.1f GB allocated in %.3f s\n", t, bytes / 1e9,
+                        std::chrono::duration<double>(std::chrono::steady_clock::now() - ta).count());
+            float ms = 0;
+            for (int rep = 0; rep < 2; rep++) {          // (the first pass faults the translations in)
+                HIP_TRY(hipEventRecord(e0, c->stream));
+                hipLaunchKernelGGL(k_probe_slots, dim3((unsigned)slots), dim3(WAVE), 0, c->stream, cand[(size_t)t].p, (int64_t)block, span, 128, sink.p);
+                HIP_TRY(hipEventRecord(e1, c->stream));
+                HIP_TRY(hipEventSynchronize(e1));
+                HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+            }
+            const double rate = (double)slots * WAVE * 128 / (ms * 1e-3) / 1e9;
+            c->placement_probe.push_back(rate);
+            if (best < 0 || rate > c->placement_probe[(size_t)best]) best = t;
+            const double slowest = *std::min_element(c->placement_probe.begin(), c->placement_probe.end());
+            if (c->placement_probe[(size_t)best] >= 1.1 * slowest) break;          // both classes seen, a fast one in hand
+            if (known_best > 0.0 && c->placement_probe[(size_t)best] >= 0.97 * known_best) break;   // as good as this process has seen
+        }
+        if (best < 0) return fail(ARCTE_HIP_EHIP, "no memory for the propagation slots");
+        return 0;
+    }();
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    sink.release();
+    if (rc) {
+        for (auto &m : cand) { m.plain.release(); m.p = nullptr; m.size = 0; }
+        return rc;
+    }
+    c->l_block.release(c->device);
+    c->l_block = cand[(size_t)best];          // (shallow: the candidate's buffer changes hands)
+    cand[(size_t)best].plain.p = nullptr;
+    cand[(size_t)best].p = nullptr;
+    {
+        // the losers are parked (see g_parked); the best rate is remembered for the next context of this shape
+        std::lock_guard<std::mutex> lock(g_big_mutex);
+        for (auto &m : cand) {
+            if (m.plain.p) g_parked.push_back({c->device, (void *)m.plain.p, m.plain.capacity});
+            m.plain.p = nullptr; m.plain.count = 0; m.plain.capacity = 0; m.p = nullptr; m.size = 0;
+        }
+        bool found = false;
+        for (auto &b : g_best_probe)
+            if (b.device == c->device && b.bytes == bytes) { b.rate = std::max(b.rate, c->placement_probe[(size_t)best]); found = true; }
+        if (!found) g_best_probe.push_back({c->device, bytes, c->placement_probe[(size_t)best]});
+        if (env_int("ARCTE_HIP_VERBOSE", 0))
+            fprintf(stderr, "[arcte_hip] slot memory: %d candidates probed, kept %d, %d buffers parked\n", (int)c->placement_probe.size(), best, (int)g_parked.size());
+    }
+    c->placement_kept = best;
+    return 0;
+}
+
 int alloc_lines(arcte_hip_ctx *c, int64_t slots, uint32_t qcap, uint32_t pcap, uint32_t scap)
 {
     // (nothing is cleared: a value is only ever read after a bitmap said its line was written by this seed)
     const LinesLayout y = lines_layout(c, qcap, pcap, scap);
-    HIP_TRY(c->l_block.alloc((size_t)slots * y.block, c->device));
+    {
+        int rd = draw_slot_memory(c, (size_t)slots, y.block);
+        if (rd) return rd;
+    }
     HIP_TRY(c->l_blockb.alloc((size_t)slots * y.blockb, c->device));
     if (const int poison = env_int("ARCTE_HIP_POISON", -1); poison >= 0) {
         // test hook: the slot memory starts as garbage of the caller's choice -- nothing may depend on what it held
@@ -871,10 +997,10 @@ int setup_lines(arcte_hip_ctx *c, uint32_t M)
     uint32_t qcap = c->want_queue > 0 ? next_pow2((uint64_t)c->want_queue) : std::min<uint32_t>(default_queue_capacity(n), 1u << 15);
     if (qcap < (uint32_t)WAVE) qcap = WAVE;
     const uint32_t node_cap = next_pow2((uint64_t)n);
-    // a seed of the 1M/50M graph pushes 190 distinct nodes (p99 600, tools/line_study.py) and lists a few thousand
-    // candidates; what does not fit is re-run with four times the room (grow_lines)
-    const uint32_t pcap = std::min<uint32_t>(node_cap, (uint32_t)std::max(64, env_int("ARCTE_HIP_PUSHED", 1024)));
-    const uint32_t scap = std::min<uint32_t>(node_cap, (uint32_t)std::max(64, env_int("ARCTE_HIP_CANDIDATES", 65536)));
+    // a seed of the 1M/50M graph pushes 190 distinct nodes (p99 600, the heaviest a few thousand: tools/line_study.py) and
+    // lists 1 300 candidates (the heaviest over 65 536); what does not fit is re-run with four times the room (grow_lines)
+    const uint32_t pcap = std::min<uint32_t>(node_cap, (uint32_t)std::max(64, env_int("ARCTE_HIP_PUSHED", 4096)));
+    const uint32_t scap = std::min<uint32_t>(node_cap, (uint32_t)std::max(64, env_int("ARCTE_HIP_CANDIDATES", 262144)));
     int64_t slots = c->want_slots;
     if (slots <= 0) {
         c->l_waves_per_cu = std::max(1, std::min(env_int("ARCTE_HIP_WAVES_PER_CU", 12), 32));
@@ -2703,6 +2829,7 @@ int arcte_hip_stream_bandwidth(int device, int64_t bytes, double *read_gbps, dou
 
 int arcte_hip_trim(void)
 {
+    free_parked_buffers();
     std::lock_guard<std::mutex> lock(g_big_mutex);
     for (auto &e : g_big_cache) {
         (void)hipSetDevice(e.device);
@@ -2788,6 +2915,15 @@ int arcte_hip_state_info(arcte_hip_ctx *c, int64_t info[12])
     info[6] = lines ? (int64_t)lines_lds_per_wave(c) : 0;
     info[7] = lines ? (int64_t)c->l_MB : 0;
     for (int i = 0; i < 4; i++) info[8 + i] = c->line_stats[i];
+    return 0;
+}
+
+int arcte_hip_placement_info(arcte_hip_ctx *c, int *kept, double *rates, int capacity, int *drawn)
+{
+    if (!c || !drawn || (capacity > 0 && !rates)) return fail(ARCTE_HIP_EINVAL, "bad argument");
+    *drawn = (int)c->placement_probe.size();
+    if (kept) *kept = c->placement_kept;
+    for (int i = 0; i < capacity && i < *drawn; i++) rates[i] = c->placement_probe[(size_t)i];
     return 0;
 }
 

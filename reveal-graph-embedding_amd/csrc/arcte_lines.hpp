@@ -680,6 +680,25 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(WPE))) voi
     }
 }
 
+// ---- placement probe: how fast are random 8-byte read-modify-writes into the slots' often touched region? --------
+// One wavefront per slot, `iters` updates per lane inside the first `span` bytes of the slot's block -- the access
+// pattern of the push kernel's line level, a couple of milliseconds.  The rate depends on how the allocation is laid
+// over the physical memory (arcte_hip.hip: lines_layout), so the library can compare candidates before it settles.
+__global__ __launch_bounds__(WAVE) void k_probe_slots(char *base, int64_t stride_bytes, uint32_t span_values, int iters, unsigned long long *sink)
+{
+    double *v = reinterpret_cast<double *>(base + (int64_t)blockIdx.x * stride_bytes);
+    uint64_t x = ((uint64_t)blockIdx.x * WAVE + threadIdx.x) * 0x9E3779B97F4A7C15ull + 1;
+    double acc = 0.0;
+    for (int it = 0; it < iters; it++) {
+        x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33;
+        double *p = v + (uint32_t)(x >> 20) % span_values;
+        const double a = *p;
+        *p = a + 1.0;
+        acc += a;
+    }
+    if (acc == 12345.678) atomicAdd(sink, 1ULL);
+}
+
 // ---- rank space: the per-node arrays by rank, the rank of every edge's target ---------------------------------
 __global__ void k_node_rank(const int32_t *ranked_ids, int64_t n, uint32_t *node_rank)
 {
