@@ -184,7 +184,10 @@ def main():
             best = min(best, c.timing()["push_ms"])
         return best
 
-    ctx, placement_ms = _native.fastest_context(make_context, calibrate, tries=args.placement_tries)
+    if args.placement_tries > 1:
+        ctx, placement_ms = _native.fastest_context(make_context, calibrate, tries=args.placement_tries)
+    else:
+        ctx, placement_ms = make_context(), []          # what arcte() does: the first context (the library places its slot memory)
     del adjacency
     seeds = ctx.seed_list()
     shard = shard_seeds(seeds, args.shards, rank)
