@@ -449,7 +449,7 @@ uint32_t lines_hot_values(const arcte_hip_ctx *c)
 {
     const int cap = env_int("ARCTE_HIP_HOT", -1);
     if (cap == 0) return 0;
-    const size_t per_wave = lines_lds_per_wave(c), bitmap = c->l_M / 8;
+    const size_t per_wave = lines_lds_per_wave(c), bitmap = c->l_M / 8 + (env_int("ARCTE_HIP_STAGE_ROWS", 0) ? 2560 : 0);
     if (per_wave <= bitmap) return 0;
     uint64_t k = (per_wave - bitmap) / sizeof(double);
     k = std::min<uint64_t>(k, (uint64_t)c->n);
@@ -656,6 +656,8 @@ int launch_lines_v(arcte_hip_ctx *c, const PushParams &P, const LineParams &L, i
     // ARCTE_HIP_TILES=2 / 4 keep the longer steps for ARCTE's worker on narrow rows (A/B).
     if (c->narrow && c->tiles == 4 && MODE == 0 && VAR == 0) return tail ? go(k_arcte_lines<0, 0, true, true, false, 4>) : go(k_arcte_lines<0, 0, true, false, false, 4>);
     if (c->narrow && c->tiles == 2 && MODE == 0 && VAR == 0) return tail ? go(k_arcte_lines<0, 0, true, true, false, 2>) : go(k_arcte_lines<0, 0, true, false, false, 2>);
+    if (c->narrow && MODE == 0 && VAR == 0 && env_int("ARCTE_HIP_STAGE_ROWS", 0))       // A/B: row data of the steps in flight staged through LDS
+        return tail ? go(k_arcte_lines<0, 0, true, true, false, 1, 1, true>) : go(k_arcte_lines<0, 0, true, false, false, 1, 1, true>);
     if (c->narrow && MODE == 0 && VAR == 0 && c->l_waves_per_cu > 12)      // four wavefronts per SIMD: the compiler spills to fit 128 VGPRs
         return tail ? go(k_arcte_lines<0, 0, true, true, false, 1, 4>) : go(k_arcte_lines<0, 0, true, false, false, 1, 4>);
     if (c->narrow) return tail ? go(k_arcte_lines<MODE, VAR, true, true, false, 1>) : go(k_arcte_lines<MODE, VAR, true, false, false, 1>);
@@ -700,7 +702,7 @@ int launch_lines(arcte_hip_ctx *c, PushParams P, int64_t nwork, int variant, int
     L.lstats = c->l_stats.p;
     P.queue = reinterpret_cast<QEntry *>(c->l_block.p + c->l_off_queue);
     P.qcap = c->l_qcap;
-    const size_t lds = (size_t)L.K * sizeof(double) + c->l_M / 8;
+    const size_t lds = (size_t)L.K * sizeof(double) + c->l_M / 8 + (env_int("ARCTE_HIP_STAGE_ROWS", 0) ? 2560 : 0);
     const int blocks = (int)std::min<int64_t>(c->l_slots, std::max<int64_t>(nwork, 1));
     if (mode == 2) return launch_lines_v<2, 0>(c, P, L, blocks, lds);
     if (c->prof.p && c->narrow && variant == 0) {

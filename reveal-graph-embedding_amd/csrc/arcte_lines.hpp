@@ -93,7 +93,7 @@ template <int LT> struct LClaimT { uint32_t old[LT]; };
 // TAIL: the graph has more ranks than the LDS bitmap covers (8 M); the others' lines have their touched-bits in a
 // per-slot bitmap in global memory (L2-resident for graphs of a few million nodes), claimed by a returning atomic OR one
 // pipeline stage before the line is written or read.
-template <int MODE, int VAR, bool NARROW, bool TAIL, bool PROF = false, int LT = 1, int WPE = 1>
+template <int MODE, int VAR, bool NARROW, bool TAIL, bool PROF = false, int LT = 1, int WPE = 1, bool STAGE = false>
 __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(WPE))) void k_arcte_lines(PushParams P, LineParams L)
 {
     typedef LRowT<LT, NARROW> LRow;
@@ -101,6 +101,10 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(WPE))) voi
     typedef LPushedT<LT> LPushed;
     typedef LClaimT<LT> LClaim;
     static_assert(MODE == 0 || MODE == 2, "worker or centrality");
+    // STAGE (A/B of BASELINE.json's "rows staged through LDS", ARCTE_HIP_STAGE_ROWS=1): the row data of the steps in flight
+    // (rank + float32 in_degree, 8 bytes per edge) go global -> LDS directly (global_load_lds), five 512-byte stages behind
+    // the bitmap, and are read back when a stage needs them, instead of living in VGPRs across the turns
+    static_assert(!STAGE || (NARROW && LT == 1), "row staging exists for one-tile steps of narrow rows");
     // PROF (ARCTE_HIP_PROFILE=1): s_memtime ticks per phase, the indices of PushParams::prof
     unsigned long long prof[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     auto tick = [&]() -> unsigned long long { return PROF ? (unsigned long long)__builtin_amdgcn_s_memtime() : 0ULL; };
@@ -112,6 +116,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(WPE))) voi
     const uint32_t Mmask = L.M - 1, Mshift = L.Mshift;
     double *hot = reinterpret_cast<double *>(lds_raw);
     uint32_t *bm = reinterpret_cast<uint32_t *>(hot + K);
+    uint32_t *ring = bm + (L.M >> 5);                 // STAGE: [5 stages][rank[64] | in_degree[64]]
     const uint32_t RA = L.M << 3;                    // first rank of region B
     const uint32_t MBmask = L.MB - 1, MBshift = L.MBshift;
     double *__restrict__ vals = L.vals + slot * L.vals_stride;
@@ -338,7 +343,51 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(WPE))) voi
                 }
             };
             constexpr int64_t STEP = LT * WAVE;
-            if (re - rb > STEP) {
+            if (STAGE && re - rb > STEP) {
+                if constexpr (STAGE) {
+                    // the row data of step j lives in ring stage j % 5 from the turn after it was requested
+                    auto request = [&](int64_t base, int stage) {
+                        const int64_t k = base + lane;
+                        const int64_t kk = k < re ? k : re - 1;
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(L.edge_rank + kk),
+                                                         (__attribute__((address_space(3))) void *)(ring + stage * 128), 4, 0, 0);
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g.edge_in_degree_f + kk),
+                                                         (__attribute__((address_space(3))) void *)(ring + stage * 128 + 64), 4, 0, 0);
+                    };
+                    auto fetch = [&](int64_t base, int stage, LRow &R) {
+                        R.a[0] = base + lane < re;
+                        R.v[0] = ring[stage * 128 + lane];
+                        R.d[0] = __uint_as_float(ring[stage * 128 + 64 + lane]);
+                    };
+                    LRow R0, R1, R2, R3;
+                    LSlot E0, E1, E2;
+                    LPushed Q0, Q1;
+                    LClaim C0, C1, C2, C3;
+                    for (int j = 0; j < 4; j++) request(rb + j * STEP, j);
+                    __builtin_amdgcn_s_waitcnt(0x0F70);
+                    fetch(rb, 0, R0); fetch(rb + STEP, 1, R1); fetch(rb + 2 * STEP, 2, R2);
+                    claim(R0, C0); claim(R1, C1); claim(R2, C2);
+                    slots(R0, E0, C0, false);
+                    slots(R1, E1, C1, false);
+                    pushed(R0, E0, Q0, false);
+                    int st = 0;                                    // ring stage of the step being processed
+                    for (int64_t base = rb; base < re; base += STEP) {
+                        __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): the row data requested last turn is in LDS
+                        fetch(base, st, R0);
+                        fetch(base + STEP, (st + 1) % 5, R1);
+                        fetch(base + 2 * STEP, (st + 2) % 5, R2);
+                        fetch(base + 3 * STEP, (st + 3) % 5, R3);
+                        pushed(R1, E1, Q1, false);
+                        process(R0, E0, Q0);
+                        slots(R2, E2, C2, false);
+                        claim(R3, C3);
+                        request(base + 4 * STEP, (st + 4) % 5);
+                        if (!ok) break;
+                        E0 = E1; E1 = E2; Q0 = Q1; C2 = C3;
+                        st = (st + 1) % 5;
+                    }
+                }
+            } else if (re - rb > STEP) {
                 LRow R0, R1, R2, R3, R4;
                 LSlot E0, E1, E2;
                 LPushed Q0, Q1;

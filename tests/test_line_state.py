@@ -125,3 +125,16 @@ def test_slot_memory_content_is_irrelevant(poison, monkeypatch):
         colptr, rows, nop, st, info = run(g, hot, lines_lds, oracle.ARCTE, monkeypatch)
         assert np.array_equal(colptr, o_colptr) and np.array_equal(nop, o_nop)
         assert np.array_equal(sorted_rows(colptr, rows), o_rows)
+
+
+def test_rows_staged_through_lds_give_the_same_results(monkeypatch):
+    """ARCTE_HIP_STAGE_ROWS=1 (A/B of the north_star's "rows staged through LDS"): global_load_lds into a ring of five
+    stages instead of VGPR stages; long rows only.  Same results."""
+    g = load_golden("rmat2000")
+    o_colptr, o_rows, _, o_nop, _ = oracle.worker(g["w"], g["out_degree"], g["in_degree"], g["all_seeds"], g["rho"], g["epsilon"],
+                                                  want_stats=True)
+    monkeypatch.setenv("ARCTE_HIP_STAGE_ROWS", "1")
+    for hot, lines_lds in ((0, 64), (16, 64), (-1, None)):
+        colptr, rows, nop, st, info = run(g, hot, lines_lds, oracle.ARCTE, monkeypatch)
+        assert np.array_equal(colptr, o_colptr) and np.array_equal(nop, o_nop)
+        assert np.array_equal(sorted_rows(colptr, rows), o_rows)
