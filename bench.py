@@ -204,7 +204,6 @@ def main():
     from reveal_graph_embedding_amd.distributed import gather_shards_begin, gather_shards_end
     nsub = args.sub_launches if args.sub_launches > 0 else (4 if world > 1 else 1)
     parts = [np.ascontiguousarray(shard[j::nsub]) for j in range(nsub)]       # interleaved: every part has the shard's mix
-    acc = {}
 
     def step():
         """One pass over the rank's shard.  Returns what the step did: kernel ms, counters, emitted rows, gather time."""

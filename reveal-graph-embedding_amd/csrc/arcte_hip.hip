@@ -1,13 +1,16 @@
-// ARCTE eps-truncated absorbing-random-walk propagation for MI355X (gfx950 / CDNA4).
+// ARCTE eps-truncated absorbing-random-walk propagation for MI355X (gfx950 / CDNA4): host side and C ABI.
 //
 // One 64-lane wavefront owns one seed at a time ("slot"): it runs the reference's strictly
 // sequential FIFO of similarity.py:149-222 exactly, and spends its 64 lanes on the edges of
 // the row being pushed (push.py:62-64: distinct targets, no conflicts).  Thousands of slots
-// are in flight per GPU, each with a private dense state vector in HBM (32-byte entries
-// {r, s, in_degree, epoch}: one 32-B sector per touched node, validity by epoch tag so nothing
-// is ever zero-filled between seeds), so the chip is kept busy by seed-level parallelism while
-// every seed keeps the reference's operation order -- which is what makes the output sparsity
-// pattern bit-exact.
+// are in flight per GPU, so the chip is kept busy by seed-level parallelism while every seed keeps the
+// reference's operation order -- which is what makes the output sparsity pattern bit-exact.
+//
+// Where a seed's state lives (csrc/arcte_lines.hpp, the default since round 3): nodes are named by rank; the
+// highest ranks keep one value in LDS, the others one float64 in strided 64-byte lines of the slot's memory whose
+// first touch is a blind whole-line write arbitrated by an LDS bitmap; pushed nodes move to a compact {r, s} array.
+// The dense-state kernel of rounds 1-2 (csrc/arcte_kernels.hpp: 32-byte {r, s, in_degree, epoch} entries) serves
+// arcte_hip_similarity_slice, float32 and the A/B knobs; its slots are made on demand.
 //
 // Arithmetic notes (all pinned by tests against the CPU oracle):
 //   - built with -ffp-contract=off: p = c*w then s+p, r+p are separate IEEE operations as in

@@ -3,9 +3,11 @@
 //
 // Same algorithm, same operation order per location as k_arcte_seeds (similarity.py:149-222, push.py:41-64,
 // arcte.py:352-376) -- what changes is WHERE a seed's state lives, because that is what the kernel is bound by.
-// Measured (tools/line_wall.hip, tools/line_study.py): the chip moves ~40 G random 64-byte requests per second whatever
+// Measured (tools/line_wall.hip, tools/line_study.py): the chip moves ~40-55 G random 64-byte requests per second whatever
 // their size or direction; a read-modify-write of a cold entry costs two of them, and 80 % of a seed's cold updates are
-// FIRST touches of their node -- the read fetches a stale line only to learn that the node is untouched.
+// FIRST touches of their node -- the read fetches a stale line only to learn that the node is untouched.  A first touch
+// that knows it is one writes blind; whole lines only (partial writes halve the rate), and the four lanes of a quad per
+// line (one store instruction = whole lines: 41.7 G mixed updates/s against 22.3 with four stores per lane).
 //
 //   * Nodes are named by RANK (descending pattern in-count) inside the kernel.  The row streams carry ranks
 //     (edge_rank), the per-node arrays are indexed by rank (rowspan, in_degree_r), results are translated back
@@ -22,8 +24,13 @@
 //   * Pushed nodes (and the seed) need r and s apart: they move to a compact per-slot array PS[j] = {r, s}, j = order
 //     of first push, and leave a NaN whose payload is j in their value's place (LDS or line level alike).  A seed
 //     pushes ~190 distinct nodes: 3 KB that stay in the L2.
-//   * The row walk is a FOUR-stage software pipeline (rows i+3, slot values i+2, pushed-state i+1, add/store/enqueue i):
-//     every stage issues its loads unconditionally, so no stage has to drain the ones behind it.
+//   * Ranks beyond the LDS bitmap's reach (>= 8 M: "region B", template flag TAIL) have the same lines with their
+//     touched-bits in a per-slot bitmap in global memory, claimed by a returning atomic one pipeline stage earlier.
+//   * The row walk is a software pipeline of 64-edge steps (rows i+4, claims i+3, slot values i+2, pushed-state i+1,
+//     add/store/enqueue i): every stage issues its loads unconditionally, and ONE vmcnt(0) at the top of a turn waits for
+//     what the previous turn issued -- the counter is in order and counts stores, which the compiler cannot count under
+//     a branch, so a wait anywhere else would drain the turn's own loads too.
+//   * Occupancy decides: one tile per step keeps the kernel at 149 VGPRs = three wavefronts per SIMD (12 per CU).
 #pragma once
 
 #include "arcte_kernels.hpp"

@@ -20,12 +20,23 @@ arm() {  # name, env assignments...
   for kv in "$@"; do unset "${kv%%=*}"; done
   echo "arm $name done"
 }
-arm a_r1_shape_tables_off ARCTE_HIP_HOT=0 ARCTE_HIP_WAVES_PER_CU=8 ARCTE_HIP_NARROW=0
-arm b_lds_table_w8 ARCTE_HIP_WAVES_PER_CU=8 ARCTE_HIP_WARM=0 ARCTE_HIP_NARROW=0
-arm c_lds_table_w4 ARCTE_HIP_WAVES_PER_CU=4 ARCTE_HIP_WARM=0 ARCTE_HIP_NARROW=0
-arm d_lds_table_w4_narrow_rows ARCTE_HIP_WAVES_PER_CU=4 ARCTE_HIP_WARM=0
-arm e_lds_warm_narrow_w4 ARCTE_HIP_WAVES_PER_CU=4
-arm f_default_lds_warm_narrow_w6
-arm g_lds_warm_narrow_w8 ARCTE_HIP_WAVES_PER_CU=8
+if [ "$ROUND" = "r02" ]; then
+arm a_r1_shape_tables_off ARCTE_HIP_STATE=dense ARCTE_HIP_HOT=0 ARCTE_HIP_WAVES_PER_CU=8 ARCTE_HIP_NARROW=0
+arm b_lds_table_w8 ARCTE_HIP_STATE=dense ARCTE_HIP_WAVES_PER_CU=8 ARCTE_HIP_WARM=0 ARCTE_HIP_NARROW=0
+arm c_lds_table_w4 ARCTE_HIP_STATE=dense ARCTE_HIP_WAVES_PER_CU=4 ARCTE_HIP_WARM=0 ARCTE_HIP_NARROW=0
+arm d_lds_table_w4_narrow_rows ARCTE_HIP_STATE=dense ARCTE_HIP_WAVES_PER_CU=4 ARCTE_HIP_WARM=0
+arm e_lds_warm_narrow_w4 ARCTE_HIP_STATE=dense ARCTE_HIP_WAVES_PER_CU=4
+arm f_default_lds_warm_narrow_w6 ARCTE_HIP_STATE=dense
+arm g_lds_warm_narrow_w8 ARCTE_HIP_STATE=dense ARCTE_HIP_WAVES_PER_CU=8
+else
+# round 3: the dense state of round 2 -> the line state, step by step (each arm = the previous + one thing)
+arm a_dense_state_r02_default ARCTE_HIP_STATE=dense
+arm b_lines_two_tiles_w8_bitmap_16k ARCTE_HIP_TILES=2 ARCTE_HIP_WAVES_PER_CU=8 ARCTE_HIP_LINES_LDS=131072
+arm c_lines_two_tiles_w8_bitmap_4k ARCTE_HIP_TILES=2 ARCTE_HIP_WAVES_PER_CU=8
+arm d_lines_one_tile_w8 ARCTE_HIP_WAVES_PER_CU=8
+arm e_lines_one_tile_w10 ARCTE_HIP_WAVES_PER_CU=10
+arm f_default_lines_one_tile_w12
+arm g_lines_one_tile_w16_spilling ARCTE_HIP_WAVES_PER_CU=16
+fi
 python3 $R/tools/summarise_experiments.py $OUT > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt

@@ -13,14 +13,14 @@ def main():
         rec = {"arm": arm}
         for path in glob.glob(os.path.join(out, arm, "trace", "**", "*kernel_stats.csv"), recursive=True):
             for r in csv.DictReader(open(path)):
-                if "k_arcte_seeds" in r["Name"]:
+                if "k_arcte_seeds" in r["Name"] or "k_arcte_lines" in r["Name"]:
                     rec["kernel"] = r["Name"].replace("void (anonymous namespace)::", "").split("((anonymous")[0]
                     rec["ms_per_launch"] = float(r["AverageNs"]) / 1e6
                     rec["launches"] = int(r["Calls"])
         for path in glob.glob(os.path.join(out, arm, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
             acc = {}
             for r in csv.DictReader(open(path)):
-                if "k_arcte_seeds" in r["Kernel_Name"]:
+                if "k_arcte_seeds" in r["Kernel_Name"] or "k_arcte_lines" in r["Kernel_Name"]:
                     a = acc.setdefault(r["Counter_Name"], [0.0, 0])
                     a[0] += float(r["Counter_Value"])
                     a[1] += 1
