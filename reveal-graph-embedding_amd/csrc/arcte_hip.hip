@@ -123,11 +123,14 @@ bool free_parked_buffers()
 {
     std::lock_guard<std::mutex> lock(g_big_mutex);
     const bool any = !g_parked.empty();
+    int current = 0;
+    const bool have_current = hipGetDevice(&current) == hipSuccess;
     for (auto &e : g_parked) {
         (void)hipSetDevice(e.device);
         (void)hipFree(e.p);
     }
     g_parked.clear();
+    if (any && have_current) (void)hipSetDevice(current);        // (the caller's allocation goes on)
     return any;
 }
 constexpr size_t BIG_BUFFER = (size_t)256 << 20;
@@ -512,7 +515,9 @@ int draw_slot_memory(arcte_hip_ctx *c, size_t slots, size_t block)
     c->placement_kept = -1;
     int tries = std::max(1, std::min(16, env_int("ARCTE_HIP_PLACEMENT_TRIES", 8)));
     // (a draw costs ~0.1 s per candidate: only for graphs whose runs are long enough to repay it)
-    if (bytes < ((size_t)1 << 30) || slots < 256 || c->n < (int64_t)env_int("ARCTE_HIP_PLACEMENT_MIN_NODES", 262144)) tries = 1;
+    if (bytes < ((size_t)std::max(1, env_int("ARCTE_HIP_PLACEMENT_MIN_MB", 1024)) << 20) || slots < 256 ||
+        c->n < (int64_t)env_int("ARCTE_HIP_PLACEMENT_MIN_NODES", 262144))
+        tries = 1;
     if (tries == 1) {
         HIP_TRY(c->l_block.alloc(bytes, c->device));
         return 0;
@@ -658,6 +663,8 @@ int launch_lines_v(arcte_hip_ctx *c, const PushParams &P, const LineParams &L, i
     // seeds: two tiles at 8 per CU 91.1; one tile at 9 / 10 / 11 / 12 per CU 89.5 / 81.4 / 78.3 / 76.4).
     // ARCTE_HIP_TILES=2 / 4 keep the longer steps for ARCTE's worker on narrow rows (A/B).
     if (c->narrow && c->tiles == 4 && MODE == 0 && VAR == 0) return tail ? go(k_arcte_lines<0, 0, true, true, false, 4>) : go(k_arcte_lines<0, 0, true, false, false, 4>);
+    if (c->narrow && c->tiles == 2 && MODE == 0 && VAR == 0 && c->l_waves_per_cu > 8)   // two tiles at three wavefronts per SIMD (168 VGPRs)
+        return tail ? go(k_arcte_lines<0, 0, true, true, false, 2, 3>) : go(k_arcte_lines<0, 0, true, false, false, 2, 3>);
     if (c->narrow && c->tiles == 2 && MODE == 0 && VAR == 0) return tail ? go(k_arcte_lines<0, 0, true, true, false, 2>) : go(k_arcte_lines<0, 0, true, false, false, 2>);
     if (c->narrow && MODE == 0 && VAR == 0 && env_int("ARCTE_HIP_STAGE_ROWS", 0))       // A/B: row data of the steps in flight staged through LDS
         return tail ? go(k_arcte_lines<0, 0, true, true, false, 1, 1, true>) : go(k_arcte_lines<0, 0, true, false, false, 1, 1, true>);

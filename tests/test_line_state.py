@@ -138,3 +138,27 @@ def test_rows_staged_through_lds_give_the_same_results(monkeypatch):
         colptr, rows, nop, st, info = run(g, hot, lines_lds, oracle.ARCTE, monkeypatch)
         assert np.array_equal(colptr, o_colptr) and np.array_equal(nop, o_nop)
         assert np.array_equal(sorted_rows(colptr, rows), o_rows)
+
+
+def test_placement_draw_is_invisible_in_the_results(monkeypatch):
+    """A context that is large enough probes candidate allocations of its slot memory and keeps the fastest (the losers are
+    parked until arcte_hip_trim()); forced onto a small graph here: same results, the draws are reported."""
+    from reveal_graph_embedding_amd import _native
+    g = load_golden("rmat2000")
+    w = g["w"]
+    with _native.Context(w.indptr, w.indices, w.data, g["out_degree"], g["in_degree"]) as ctx:
+        assert ctx.placement_info() == (-1, [])                      # too small to care by default
+    o_colptr, o_rows, _, o_nop, _ = oracle.worker(w, g["out_degree"], g["in_degree"], g["all_seeds"], g["rho"], g["epsilon"], want_stats=True)
+    monkeypatch.setenv("ARCTE_HIP_PLACEMENT_MIN_NODES", "1")
+    monkeypatch.setenv("ARCTE_HIP_PLACEMENT_MIN_MB", "1")
+    monkeypatch.setenv("ARCTE_HIP_PLACEMENT_TRIES", "4")
+    try:
+        with _native.Context(w.indptr, w.indices, w.data, g["out_degree"], g["in_degree"]) as ctx:
+            kept, rates = ctx.placement_info()
+            assert 1 <= len(rates) <= 4 and 0 <= kept < len(rates) and all(r > 0 for r in rates)
+            ctx.run_seeds(g["all_seeds"], g["rho"], g["epsilon"])
+            colptr, rows, nop = ctx.fetch(want_nop=True)
+        assert np.array_equal(colptr, o_colptr) and np.array_equal(nop, o_nop)
+        assert np.array_equal(sorted_rows(colptr, rows), o_rows)
+    finally:
+        _native.trim()
