@@ -113,6 +113,8 @@ def main():
     ap.add_argument("--rho", type=float, default=0.1)
     ap.add_argument("--epsilon", type=float, default=1e-5)
     ap.add_argument("--slots", type=int, default=0)
+    ap.add_argument("--ballast-gb", type=float, default=0.0,
+                    help="experiment: hold this much device memory beside the context (how the kernel's duration depends on the device's fill)")
     ap.add_argument("--placement-tries", type=int, default=1,
                     help="contexts drawn before the run, the fastest on a calibration sample is kept; 1 (default) = take the "
                          "first, which is what arcte(), arcte_worker() and the console script do")
@@ -172,6 +174,10 @@ def main():
     adjacency = load_graph(args.nodes, args.edges, 0, local_rank, barrier)
     nnz = int(adjacency.nnz)
     w_indptr, w_indices = adjacency.indptr, adjacency.indices          # pattern of W = pattern of A (--verify)
+    ballast = torch.empty(int(args.ballast_gb * 1e9), dtype=torch.uint8, device=dev) if args.ballast_gb > 0 else None
+    if ballast is not None:
+        ballast.fill_(1)
+
     def make_context():
         return _native.Context.from_adjacency(adjacency.indptr, adjacency.indices, adjacency.data, device=gpu, n_slots=args.slots)
 
@@ -194,8 +200,9 @@ def main():
     info = ctx.info()
     state = ctx.state_info()
     placement_kept, placement_rates = ctx.placement_info()
-    log("[bench] rank %d: n=%d nnz=%d seeds=%d shard=%d slots=%d device_bytes=%.1f GB" % (
-        rank, args.nodes, nnz, seeds.size, shard.size, info["slots"], info["device_bytes"] / 1e9))
+    mem_free, mem_total = torch.cuda.mem_get_info(dev)
+    log("[bench] rank %d: n=%d nnz=%d seeds=%d shard=%d slots=%d device_bytes=%.1f GB (device: %.1f of %.1f GB free)" % (
+        rank, args.nodes, nnz, seeds.size, shard.size, info["slots"], info["device_bytes"] / 1e9, mem_free / 1e9, mem_total / 1e9))
 
     variant = {"arcte": _native.ARCTE, "pagerank": _native.PAGERANK, "lazy": _native.LAZY_PAGERANK}[args.variant]
     run_rho = (args.rho * 0.5) / (1 - 0.5 * args.rho) if args.variant == "lazy" else args.rho   # arcte.py:109

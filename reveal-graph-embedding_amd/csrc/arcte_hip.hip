@@ -292,6 +292,7 @@ struct arcte_hip_ctx {
     // state | region B bits], and one for region B's values; both sizes are powers of two (lines_layout)
     SlotMem l_block, l_blockb;
     size_t l_block_bytes = 0, l_blockb_bytes = 0, l_off_queue = 0, l_off_sup = 0, l_off_ps = 0, l_off_gbm = 0, l_off_b = 0;
+    size_t l_spread = 0;          // > 0: ONE allocation, a slot every max(l_spread, what it needs) bytes, region B behind its hot block
     DevBuf<unsigned long long> l_stats;
     int64_t line_stats[4] = {0, 0, 0, 0};   // last run: LDS updates, blind line writes, read-modify-writes, updates of pushed nodes
     std::vector<double> placement_probe;    // G updates/s of every candidate allocation of the slot memory, in draw order
@@ -487,9 +488,18 @@ LinesLayout lines_layout(const arcte_hip_ctx *c, uint32_t qcap, uint32_t pcap, u
     const bool pow2 = env_int("ARCTE_HIP_SLOT_POW2", 1) != 0;         // 0: whole 2 MB pages only (A/B)
     const bool split = env_int("ARCTE_HIP_SLOT_SPLIT", 1) != 0;       // 1: region B's values in an allocation of their own (A/B)
     const size_t bytes_b = ((size_t)c->l_MB << 3) * sizeof(double);   // (MB is a power of two)
+    auto pow2_size = [&](size_t x) { size_t p = 4096; while (p < x) p <<= 1; return p; };
+    if (c->l_spread) {
+        // slots SPREAD over the device (see setup_lines): the hot block at the start of the slot's stride, region B's values
+        // behind it, the rest of the stride unused
+        const size_t hot = pow2 ? pow2_size(o) : up(o, (size_t)2 << 20);
+        y.off_b = hot;
+        y.block = std::max(up(hot + bytes_b, (size_t)2 << 20), c->l_spread);
+        y.blockb = 0;
+        return y;
+    }
     y.off_b = o;
     if (!split) o += bytes_b;
-    auto pow2_size = [&](size_t x) { size_t p = 4096; while (p < x) p <<= 1; return p; };
     y.block = pow2 ? pow2_size(o) : up(o, (size_t)2 << 20);
     y.blockb = split ? bytes_b : 0;
     return y;
@@ -522,6 +532,7 @@ int draw_slot_memory(arcte_hip_ctx *c, size_t slots, size_t block)
         HIP_TRY(c->l_block.alloc(bytes, c->device));
         return 0;
     }
+    if (c->l_spread) tries = std::min(tries, std::max(1, env_int("ARCTE_HIP_SPREAD_TRIES", 3)));      // (candidates of 50 GB and more)
     std::vector<SlotMem> cand((size_t)tries);
     DevBuf<unsigned long long> sink;
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -1014,14 +1025,40 @@ int setup_lines(arcte_hip_ctx *c, uint32_t M)
     const uint32_t pcap = std::min<uint32_t>(node_cap, (uint32_t)std::max(64, env_int("ARCTE_HIP_PUSHED", 4096)));
     const uint32_t scap = std::min<uint32_t>(node_cap, (uint32_t)std::max(64, env_int("ARCTE_HIP_CANDIDATES", 262144)));
     int64_t slots = c->want_slots;
-    if (slots <= 0) {
+    const bool auto_slots = slots <= 0;
+    if (auto_slots) {
         c->l_waves_per_cu = std::max(1, std::min(env_int("ARCTE_HIP_WAVES_PER_CU", 12), 32));
         slots = (int64_t)c->l_waves_per_cu * c->cus;
-        size_t free_b = 0, total_b = 0;
-        HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-        free_b += cached_bytes_on(c->device);
-        while (slots > c->cus && (size_t)slots * lines_bytes_per_slot(c, qcap, pcap, scap) > free_b / 20 * 17) slots -= c->cus / 2;
     }
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    free_b += cached_bytes_on(c->device);
+    // What the slot memory may take: the device's memory stays under 72 % full.  (8M-node graph, 3 072 slots of 71 MB: the
+    // kernel takes 510 ms per 392 829 seeds with 225 GB of the 309 GB in use and 790-800 ms with 227 GB or more -- whoever
+    // holds the other bytes: profiles/r03/device_fill_8m.txt.)
+    const size_t used_b = total_b > free_b ? total_b - free_b : 0;
+    const size_t budget = std::min<size_t>(free_b / 20 * 17, total_b / 100 * 72 > used_b ? total_b / 100 * 72 - used_b : 0);
+    // Slots SPREAD over the device.  The kernel's speed follows how far apart the slots' often touched bytes lie in the
+    // device's memory (tools/mem_class_map.hip, G random updates/s of 3 072 wavefronts, each inside 2 MB of its slot):
+    // slots packed into 12 GB 20.3 or 24.3 by allocation (the lottery of DESIGN.md section 5), the same at the start of a
+    // 200 GB allocation 20.3 every time, one slot every 16 MB of 48 GB 24.2, every 32 MB of 96 GB 26.7 and every 64 MB of
+    // 200 GB 25.9 on one box; the push kernel on the 1M/50M graph: 72.3 ms per 81 434 seeds with a slot every 16 MB (probe
+    // 26.2) against 75.5-78.5 packed on its fast class (24).  So a context that is large enough to care takes ONE
+    // allocation with a slot every ARCTE_HIP_SLOT_SPREAD_MB (16) and leaves the bytes between the slots unused, when the
+    // device has the room; the packed layout is what remains otherwise (several contexts on one GPU).  The levels exist
+    // for spread slots too (another box: 23.8 / 23.9 / 20.0 in three processes), so the placement draw stays, over fewer
+    // candidates.
+    c->l_spread = 0;
+    if (const int spread_mb = env_int("ARCTE_HIP_SLOT_SPREAD_MB", 16);
+        spread_mb > 0 && slots >= 256 && n >= (int64_t)env_int("ARCTE_HIP_PLACEMENT_MIN_NODES", 262144)) {
+        c->l_spread = 1;                                          // (1: behind one another without padding)
+        const size_t needed = lines_bytes_per_slot(c, qcap, pcap, scap);
+        size_t stride = (size_t)spread_mb << 20;
+        while (stride > needed && (size_t)slots * stride > std::min<size_t>(budget, total_b / 100 * 40)) stride >>= 1;
+        c->l_spread = stride > needed ? stride : ((size_t)slots * needed >= ((size_t)64 << 30) ? needed : 0);
+    }
+    if (auto_slots)
+        while (slots > c->cus && (size_t)slots * lines_bytes_per_slot(c, qcap, pcap, scap) > budget) slots -= c->cus / 2;
     slots = std::max<int64_t>(1, slots);
     c->l_waves_per_cu = (int)std::max<int64_t>(1, std::min<int64_t>(32, (slots + c->cus - 1) / c->cus));
     return alloc_lines(c, slots, qcap, pcap, scap);
@@ -1111,11 +1148,12 @@ int ctx_finish(arcte_hip_ctx *c, int64_t n_slots, int64_t queue_capacity)
     c->want_slots = n_slots;
     c->want_queue = queue_capacity;
     // ---- which state?  Lines (arcte_lines.hpp) unless the dense state is asked for.  The LDS bitmap covers the
-    //      8 M highest-ranked nodes, M = ARCTE_HIP_LINES_LDS at most: on the 1M/50M graph 99.4 % of the traversed edges
-    //      point at the 524 288 highest-ranked nodes (tools/line_study.py), and 8 KB of LDS are worth more as on-chip
-    //      values than as touched-bits of lines that a seed meets once in a hundred times
+    //      8 M highest-ranked nodes, M = ARCTE_HIP_LINES_LDS at most.  On the 1M/50M graph 99.4 % of the traversed edges
+    //      point at the 524 288 highest-ranked nodes (tools/line_study.py); at twelve wavefronts per CU (12 KB of LDS
+    //      each) a bitmap of 8 KB + 512 on-chip values beats 4 KB + 1 024 and 2 KB + 1 280 (ms per 81 434 seeds, interleaved
+    //      processes on one box: 78.2 / 83.0 / 85.6; 4M-node graph 282 / 290), and 16 KB leaves no wavefront its share
     const char *state_env = getenv("ARCTE_HIP_STATE");
-    const uint32_t lines_lds = next_pow2((uint64_t)std::max(64, env_int("ARCTE_HIP_LINES_LDS", 32768)));
+    const uint32_t lines_lds = next_pow2((uint64_t)std::max(64, env_int("ARCTE_HIP_LINES_LDS", 65536)));
     const uint32_t M = std::min<uint32_t>(lines_lds, std::max<uint32_t>(64u, next_pow2((uint64_t)((n + 7) / 8))));
     c->lines = !(state_env && state_env[0] == 'd') && !c->coop;
     int r = c->lines ? setup_lines(c, M) : setup_dense(c, n_slots, queue_capacity);

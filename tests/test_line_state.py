@@ -152,10 +152,42 @@ def test_placement_draw_is_invisible_in_the_results(monkeypatch):
     monkeypatch.setenv("ARCTE_HIP_PLACEMENT_MIN_NODES", "1")
     monkeypatch.setenv("ARCTE_HIP_PLACEMENT_MIN_MB", "1")
     monkeypatch.setenv("ARCTE_HIP_PLACEMENT_TRIES", "4")
+    monkeypatch.setenv("ARCTE_HIP_SLOT_SPREAD_MB", "0")              # the packed layout (hot blocks and region B apart)
     try:
         with _native.Context(w.indptr, w.indices, w.data, g["out_degree"], g["in_degree"]) as ctx:
             kept, rates = ctx.placement_info()
             assert 1 <= len(rates) <= 4 and 0 <= kept < len(rates) and all(r > 0 for r in rates)
+            ctx.run_seeds(g["all_seeds"], g["rho"], g["epsilon"])
+            colptr, rows, nop = ctx.fetch(want_nop=True)
+        assert np.array_equal(colptr, o_colptr) and np.array_equal(nop, o_nop)
+        assert np.array_equal(sorted_rows(colptr, rows), o_rows)
+    finally:
+        _native.trim()
+
+
+@pytest.mark.parametrize("lines_lds", [0, 64])
+def test_slots_spread_over_one_allocation(lines_lds, monkeypatch):
+    """Large contexts lay their slots out with a fixed stride inside ONE allocation, region B's values behind the slot's hot
+    block and unused bytes up to the next slot (csrc/arcte_hip.hip, setup_lines); forced onto a small graph here, with and
+    without a region B, under the placement draw: same results."""
+    from reveal_graph_embedding_amd import _native
+    g = load_golden("rmat2000")
+    w = g["w"]
+    o_colptr, o_rows, _, o_nop, _ = oracle.worker(w, g["out_degree"], g["in_degree"], g["all_seeds"], g["rho"], g["epsilon"], want_stats=True)
+    monkeypatch.setenv("ARCTE_HIP_PLACEMENT_MIN_NODES", "1")
+    monkeypatch.setenv("ARCTE_HIP_PLACEMENT_MIN_MB", "1")
+    monkeypatch.setenv("ARCTE_HIP_SPREAD_TRIES", "2")
+    monkeypatch.setenv("ARCTE_HIP_SLOT_SPREAD_MB", "4")
+    if lines_lds:
+        monkeypatch.setenv("ARCTE_HIP_LINES_LDS", str(lines_lds))
+        monkeypatch.setenv("ARCTE_HIP_HOT", "0")
+    try:
+        with _native.Context(w.indptr, w.indices, w.data, g["out_degree"], g["in_degree"]) as ctx:
+            state = ctx.state_info()
+            assert state["slot_bytes"] == ctx.info()["slots"] * (4 << 20)          # one slot every 4 MB
+            assert (state["lines_region_b"] > 0) == bool(lines_lds)
+            kept, rates = ctx.placement_info()
+            assert 1 <= len(rates) <= 2 and 0 <= kept < len(rates)
             ctx.run_seeds(g["all_seeds"], g["rho"], g["epsilon"])
             colptr, rows, nop = ctx.fetch(want_nop=True)
         assert np.array_equal(colptr, o_colptr) and np.array_equal(nop, o_nop)
