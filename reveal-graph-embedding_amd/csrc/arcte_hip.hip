@@ -474,7 +474,9 @@ uint32_t lines_hot_values(const arcte_hip_ctx *c)
 // Translations are cached for aligned power-of-two ranges; a slot that starts at an odd multiple of 2 MB is served by
 // 2 MB ranges, one that starts at a multiple of its size by one range.  So: the often touched parts -- region A's values,
 // the ring, the candidate list, the pushed-state array, region B's touched-bits -- form ONE block of power-of-two size
-// (4 MB with the default capacities), and region B's values, touched by a few per cent of the updates, another.
+// (8 MB with the default capacities), and region B's values, touched by a few per cent of the updates, another.
+// That is the PACKED layout; a context that is large enough and finds the room spreads its slots over one allocation
+// instead (l_spread, see setup_lines): the same hot block at the start of every slot's stride, region B behind it.
 struct LinesLayout { size_t off_queue, off_sup, off_ps, off_gbm, off_b, block, blockb; };
 LinesLayout lines_layout(const arcte_hip_ctx *c, uint32_t qcap, uint32_t pcap, uint32_t scap)
 {
@@ -512,12 +514,13 @@ size_t lines_bytes_per_slot(const arcte_hip_ctx *c, uint32_t qcap, uint32_t pcap
 }
 
 // The slot memory's placement decides the propagation kernel's speed (two main levels 23 % apart),
-// and hipMalloc leaves it to chance.  So a context that is large enough to care draws up to ARCTE_HIP_PLACEMENT_TRIES (3)
-// candidate allocations -- alive at the same time, so that they are different memory --, runs k_probe_slots on each (a
-// few milliseconds of the kernel's own access pattern) and keeps the fastest; the others are freed.  The probe sees two
-// classes of memory (24 and 20 G updates/s on the 1M/50M graph's slots, and the push kernel runs 646 or 777 ms on them):
-// the draw stops as soon as it holds a candidate 10 % faster than another one.  Every caller gets this -- arcte(), the
-// console script, bench.py alike.  A draw is skipped when the device has no room for another candidate.
+// and hipMalloc leaves it to chance.  So a context that is large enough to care draws up to ARCTE_HIP_PLACEMENT_TRIES (8;
+// ARCTE_HIP_SPREAD_TRIES = 3 of the much larger spread layout) candidate allocations -- alive at the same time, so that
+// they are different memory --, runs k_probe_slots on each (a few milliseconds of the kernel's own access pattern) and
+// keeps the fastest; the others are parked (g_parked).  The probe sees levels of memory (20, 22, 24 and 26 G updates/s
+// on the 1M/50M graph's slots; the push kernel runs 93 / 85 / 78 / 72 ms per 81 434 seeds on them): the draw stops as
+// soon as it holds a candidate 10 % faster than another one.  Every caller gets this -- arcte(), the console script,
+// bench.py alike.  A draw ends when the device has no room for another candidate.
 int draw_slot_memory(arcte_hip_ctx *c, size_t slots, size_t block)
 {
     const size_t bytes = slots * block;
