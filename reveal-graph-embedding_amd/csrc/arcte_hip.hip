@@ -1036,11 +1036,12 @@ int setup_lines(arcte_hip_ctx *c, uint32_t M)
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
     free_b += cached_bytes_on(c->device);
-    // What the slot memory may take: the device's memory stays under 72 % full.  (8M-node graph, 3 072 slots of 71 MB: the
-    // kernel takes 510 ms per 392 829 seeds with 225 GB of the 309 GB in use and 790-800 ms with 227 GB or more -- whoever
-    // holds the other bytes: profiles/r03/device_fill_8m.txt.)
+    // What the slot memory may take: with it the device stays under 65 % full.  (8M-node graph, 3 072 slots of 71 MB: the
+    // kernel takes 510 ms per 392 829 seeds with 225 GB of the 309 GB in use when the slots are allocated and 790-800 ms
+    // with 227 GB or more, whoever holds the other bytes; slots that are re-allocated after the output buffers exist -- a
+    // seed outgrew its pushed-state array -- fall off the same edge at 219 GB: profiles/r03/device_fill_8m.txt.)
     const size_t used_b = total_b > free_b ? total_b - free_b : 0;
-    const size_t budget = std::min<size_t>(free_b / 20 * 17, total_b / 100 * 72 > used_b ? total_b / 100 * 72 - used_b : 0);
+    const size_t budget = std::min<size_t>(free_b / 20 * 17, total_b / 100 * 65 > used_b ? total_b / 100 * 65 - used_b : 0);
     // Slots SPREAD over the device.  The kernel's speed follows how far apart the slots' often touched bytes lie in the
     // device's memory (tools/mem_class_map.hip, G random updates/s of 3 072 wavefronts, each inside 2 MB of its slot):
     // slots packed into 12 GB 20.3 or 24.3 by allocation (the lottery of DESIGN.md section 5), the same at the start of a
