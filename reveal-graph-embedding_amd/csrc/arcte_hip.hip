@@ -1065,7 +1065,19 @@ int setup_lines(arcte_hip_ctx *c, uint32_t M)
         while (slots > c->cus && (size_t)slots * lines_bytes_per_slot(c, qcap, pcap, scap) > budget) slots -= c->cus / 2;
     slots = std::max<int64_t>(1, slots);
     c->l_waves_per_cu = (int)std::max<int64_t>(1, std::min<int64_t>(32, (slots + c->cus - 1) / c->cus));
-    return alloc_lines(c, slots, qcap, pcap, scap);
+    int r = (c->l_spread && env_int("ARCTE_HIP_TEST_SPREAD_FAILS", 0)) ? fail(ARCTE_HIP_EHIP, "test hook: no room for spread slots")
+                                                                           : alloc_lines(c, slots, qcap, pcap, scap);
+    if (r && c->l_spread) {
+        // the room that was there a moment ago has gone (another context of this process, another process): packed slots
+        const size_t needed_packed = [&] { c->l_spread = 0; return lines_bytes_per_slot(c, qcap, pcap, scap); }();
+        if (auto_slots)
+            while (slots > c->cus && (size_t)slots * needed_packed > budget) slots -= c->cus / 2;
+        c->l_waves_per_cu = (int)std::max<int64_t>(1, std::min<int64_t>(32, (slots + c->cus - 1) / c->cus));
+        c->l_block.release(c->device);
+        c->l_blockb.release(c->device);
+        r = alloc_lines(c, slots, qcap, pcap, scap);
+    }
+    return r;
 }
 
 // Everything after the transition matrix and the degree vectors are on the device (indptr, indices, data,

@@ -194,3 +194,23 @@ def test_slots_spread_over_one_allocation(lines_lds, monkeypatch):
         assert np.array_equal(sorted_rows(colptr, rows), o_rows)
     finally:
         _native.trim()
+
+
+def test_spread_slots_fall_back_to_packed_ones(monkeypatch):
+    """When the one large allocation of the spread layout cannot be had (test hook), the context packs its slots: same results."""
+    from reveal_graph_embedding_amd import _native
+    g = load_golden("rmat2000")
+    w = g["w"]
+    o_colptr, o_rows, _, o_nop, _ = oracle.worker(w, g["out_degree"], g["in_degree"], g["all_seeds"], g["rho"], g["epsilon"], want_stats=True)
+    monkeypatch.setenv("ARCTE_HIP_PLACEMENT_MIN_NODES", "1")
+    monkeypatch.setenv("ARCTE_HIP_SLOT_SPREAD_MB", "4")
+    monkeypatch.setenv("ARCTE_HIP_TEST_SPREAD_FAILS", "1")
+    try:
+        with _native.Context(w.indptr, w.indices, w.data, g["out_degree"], g["in_degree"]) as ctx:
+            assert ctx.state_info()["slot_bytes"] < ctx.info()["slots"] * (4 << 20)          # packed
+            ctx.run_seeds(g["all_seeds"], g["rho"], g["epsilon"])
+            colptr, rows, nop = ctx.fetch(want_nop=True)
+        assert np.array_equal(colptr, o_colptr) and np.array_equal(nop, o_nop)
+        assert np.array_equal(sorted_rows(colptr, rows), o_rows)
+    finally:
+        _native.trim()
