@@ -292,6 +292,9 @@ struct arcte_hip_ctx {
     // state | region B bits], and one for region B's values; both sizes are powers of two (lines_layout)
     SlotMem l_block, l_blockb;
     size_t l_block_bytes = 0, l_blockb_bytes = 0, l_off_queue = 0, l_off_sup = 0, l_off_ps = 0, l_off_gbm = 0, l_off_b = 0;
+    int l_ind = 0;                // region B's lines are indirect (arcte_lines.hpp, IND): bidx table + pool instead of 8 bytes per node
+    uint32_t l_pool = 0;          // pool lines per slot
+    DevBuf<uint32_t> l_gen;       // [slots] last seed generation of every slot
     size_t l_spread = 0;          // > 0: ONE allocation, a slot every max(l_spread, what it needs) bytes, region B behind its hot block
     DevBuf<unsigned long long> l_stats;
     int64_t line_stats[4] = {0, 0, 0, 0};   // last run: LDS updates, blind line writes, read-modify-writes, updates of pushed nodes
@@ -489,7 +492,9 @@ LinesLayout lines_layout(const arcte_hip_ctx *c, uint32_t qcap, uint32_t pcap, u
     y.off_gbm = o;   o += up((size_t)(c->l_MB >> 5) * sizeof(uint32_t), 256);
     const bool pow2 = env_int("ARCTE_HIP_SLOT_POW2", 1) != 0;         // 0: whole 2 MB pages only (A/B)
     const bool split = env_int("ARCTE_HIP_SLOT_SPLIT", 1) != 0;       // 1: region B's values in an allocation of their own (A/B)
-    const size_t bytes_b = ((size_t)c->l_MB << 3) * sizeof(double);   // (MB is a power of two)
+    // region B per slot: eight float64 per line, or (indirect lines) an 8-byte entry per line + the pool's lines
+    const size_t bytes_b = c->l_ind ? (size_t)c->l_MB * sizeof(uint64_t) + (size_t)c->l_pool * 64
+                                    : ((size_t)c->l_MB << 3) * sizeof(double);   // (MB is a power of two)
     auto pow2_size = [&](size_t x) { size_t p = 4096; while (p < x) p <<= 1; return p; };
     if (c->l_spread) {
         // slots SPREAD over the device (see setup_lines): the hot block at the start of the slot's stride, region B's values
@@ -625,6 +630,14 @@ int alloc_lines(arcte_hip_ctx *c, int64_t slots, uint32_t qcap, uint32_t pcap, u
     }
     c->l_block_bytes = y.block;
     c->l_blockb_bytes = y.blockb;
+    if (c->l_ind && c->l_MB) {
+        // indirect lines: an entry is valid when it carries the generation of the seed in hand; generations count from 1
+        // per slot and allocation, so the entries start as zeros (the one thing in a slot that is ever cleared: once)
+        char *bpart = y.blockb ? c->l_blockb.p : c->l_block.p + y.off_b;
+        HIP_TRY(hipMemset2DAsync(bpart, y.blockb ? y.blockb : y.block, 0, (size_t)c->l_MB * sizeof(uint64_t), (size_t)slots, c->stream));
+        HIP_TRY(c->l_gen.alloc((size_t)slots));
+        HIP_TRY(hipMemsetAsync(c->l_gen.p, 0, c->l_gen.bytes(), c->stream));
+    }
     c->l_off_queue = y.off_queue; c->l_off_sup = y.off_sup; c->l_off_ps = y.off_ps; c->l_off_gbm = y.off_gbm; c->l_off_b = y.off_b;
     if (!c->l_stats.p) HIP_TRY(c->l_stats.alloc(4));
     c->l_slots = slots;
@@ -636,7 +649,7 @@ int alloc_lines(arcte_hip_ctx *c, int64_t slots, uint32_t qcap, uint32_t pcap, u
 
 // a seed ran out of ring, pushed-state or candidate entries: four times as many of those (never more than a seed can
 // need), fewer slots if that is what the memory allows
-int grow_lines(arcte_hip_ctx *c, bool queue_over, bool pushed_over, bool sup_over)
+int grow_lines(arcte_hip_ctx *c, bool queue_over, bool pushed_over, bool sup_over, bool pool_over = false)
 {
     uint32_t qcap = c->l_qcap, pcap = c->l_pcap, scap = c->l_scap;
     const uint32_t node_cap = next_pow2((uint64_t)c->n);
@@ -651,6 +664,10 @@ int grow_lines(arcte_hip_ctx *c, bool queue_over, bool pushed_over, bool sup_ove
     if (sup_over) {
         if (scap >= node_cap) return fail(ARCTE_HIP_ECAPACITY, "candidate list already holds every node");
         scap = std::min<uint32_t>(node_cap, scap * 4);
+    }
+    if (pool_over) {
+        if (c->l_pool >= c->l_MB) return fail(ARCTE_HIP_ECAPACITY, "region B's pool already holds every line");
+        c->l_pool = std::min<uint32_t>(c->l_MB, c->l_pool * 4);
     }
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
@@ -676,6 +693,8 @@ int launch_lines_v(arcte_hip_ctx *c, const PushParams &P, const LineParams &L, i
     // two tiles), and the kernel wants wavefronts in flight more than it wants long steps (1M/50M graph, ms per 81 434
     // seeds: two tiles at 8 per CU 91.1; one tile at 9 / 10 / 11 / 12 per CU 89.5 / 81.4 / 78.3 / 76.4).
     // ARCTE_HIP_TILES=2 / 4 keep the longer steps for ARCTE's worker on narrow rows (A/B).
+    if (tail && c->l_ind)          // region B's lines indirect
+        return c->narrow ? go(k_arcte_lines<MODE, VAR, true, true, false, 1, 1, false, true>) : go(k_arcte_lines<MODE, VAR, false, true, false, 1, 1, false, true>);
     if (c->narrow && c->tiles == 4 && MODE == 0 && VAR == 0) return tail ? go(k_arcte_lines<0, 0, true, true, false, 4>) : go(k_arcte_lines<0, 0, true, false, false, 4>);
     if (c->narrow && c->tiles == 2 && MODE == 0 && VAR == 0 && c->l_waves_per_cu > 8)   // two tiles at three wavefronts per SIMD (168 VGPRs)
         return tail ? go(k_arcte_lines<0, 0, true, true, false, 2, 3>) : go(k_arcte_lines<0, 0, true, false, false, 2, 3>);
@@ -701,12 +720,18 @@ int launch_lines(arcte_hip_ctx *c, PushParams P, int64_t nwork, int variant, int
     // B's lines continuing region A's)
     char *block = c->l_block.p;
     L.vals = reinterpret_cast<double *>(block);
-    if (c->l_blockb_bytes) {          // region B's values in an allocation of their own
-        L.vals_b = reinterpret_cast<double *>(c->l_blockb.p) - ((int64_t)c->l_M << 3);      // indexed from region A's first line
-        L.valsb_stride = (int64_t)(c->l_blockb_bytes / sizeof(double));
-    } else {
-        L.vals_b = reinterpret_cast<double *>(block + c->l_off_b) - ((int64_t)c->l_M << 3);
-        L.valsb_stride = (int64_t)(c->l_block_bytes / sizeof(double));
+    {
+        // region B's part of a slot: in an allocation of its own (packed layout) or behind the hot block; with indirect
+        // lines the entries come first and the pool's lines are what the kernel addresses as region B's values
+        char *bpart = c->l_blockb_bytes ? c->l_blockb.p : block + c->l_off_b;
+        const size_t bstride = c->l_blockb_bytes ? c->l_blockb_bytes : c->l_block_bytes;
+        const size_t entries = c->l_ind ? (size_t)c->l_MB * sizeof(uint64_t) : 0;
+        L.bidx = reinterpret_cast<uint64_t *>(bpart);
+        L.bidx_stride = (int64_t)(bstride / sizeof(uint64_t));
+        L.bgen = c->l_gen.p;
+        L.pool_cap = c->l_pool;
+        L.vals_b = reinterpret_cast<double *>(bpart + entries) - ((int64_t)c->l_M << 3);      // indexed from region A's first line
+        L.valsb_stride = (int64_t)(bstride / sizeof(double));
     }
     L.ps = reinterpret_cast<double2 *>(block + c->l_off_ps);
     L.sup = reinterpret_cast<int32_t *>(block + c->l_off_sup);
@@ -729,7 +754,7 @@ int launch_lines(arcte_hip_ctx *c, PushParams P, int64_t nwork, int variant, int
     const size_t lds = (size_t)L.K * sizeof(double) + c->l_M / 8 + (env_int("ARCTE_HIP_STAGE_ROWS", 0) ? 2560 : 0);
     const int blocks = (int)std::min<int64_t>(c->l_slots, std::max<int64_t>(nwork, 1));
     if (mode == 2) return launch_lines_v<2, 0>(c, P, L, blocks, lds);
-    if (c->prof.p && c->narrow && variant == 0) {
+    if (c->prof.p && c->narrow && variant == 0 && !c->l_ind) {
         auto kernel = c->l_MB > 0 ? k_arcte_lines<0, 0, true, true, true, 1> : k_arcte_lines<0, 0, true, false, true, 1>;
         if (lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kernel, dim3(blocks), dim3(WAVE), lds, c->stream, P, L);
@@ -1027,6 +1052,13 @@ int setup_lines(arcte_hip_ctx *c, uint32_t M)
     // lists 1 300 candidates (the heaviest over 65 536); what does not fit is re-run with four times the room (grow_lines)
     const uint32_t pcap = std::min<uint32_t>(node_cap, (uint32_t)std::max(64, env_int("ARCTE_HIP_PUSHED", 4096)));
     const uint32_t scap = std::min<uint32_t>(node_cap, (uint32_t)std::max(64, env_int("ARCTE_HIP_CANDIDATES", 262144)));
+    // region B dense (8 bytes per node and slot) or indirect (8 bytes per LINE + a pool of lines: arcte_lines.hpp, IND)?
+    // ARCTE_HIP_B_INDIRECT = 1 / 0 decides; by default (below) indirect only when the dense region would cost wavefronts
+    {
+        const int want = env_int("ARCTE_HIP_B_INDIRECT", -1);
+        c->l_ind = c->l_MB > 0 && want == 1;
+        c->l_pool = std::min<uint32_t>(c->l_MB, (uint32_t)std::max(64, env_int("ARCTE_HIP_B_POOL", 32768)));
+    }
     int64_t slots = c->want_slots;
     const bool auto_slots = slots <= 0;
     if (auto_slots) {
@@ -1052,17 +1084,30 @@ int setup_lines(arcte_hip_ctx *c, uint32_t M)
     // device has the room; the packed layout is what remains otherwise (several contexts on one GPU).  The levels exist
     // for spread slots too (another box: 23.8 / 23.9 / 20.0 in three processes), so the placement draw stays, over fewer
     // candidates.
-    c->l_spread = 0;
-    if (const int spread_mb = env_int("ARCTE_HIP_SLOT_SPREAD_MB", 16);
-        spread_mb > 0 && slots >= 256 && n >= (int64_t)env_int("ARCTE_HIP_PLACEMENT_MIN_NODES", 262144)) {
+    auto decide_spread = [&]() {
+        c->l_spread = 0;
+        const int spread_mb = env_int("ARCTE_HIP_SLOT_SPREAD_MB", 16);
+        if (spread_mb <= 0 || slots < 256 || n < (int64_t)env_int("ARCTE_HIP_PLACEMENT_MIN_NODES", 262144)) return;
         c->l_spread = 1;                                          // (1: behind one another without padding)
         const size_t needed = lines_bytes_per_slot(c, qcap, pcap, scap);
         size_t stride = (size_t)spread_mb << 20;
         while (stride > needed && (size_t)slots * stride > std::min<size_t>(budget, total_b / 100 * 40)) stride >>= 1;
         c->l_spread = stride > needed ? stride : ((size_t)slots * needed >= ((size_t)64 << 30) ? needed : 0);
-    }
-    if (auto_slots)
+    };
+    decide_spread();
+    if (auto_slots) {
+        const int64_t asked = slots;
         while (slots > c->cus && (size_t)slots * lines_bytes_per_slot(c, qcap, pcap, scap) > budget) slots -= c->cus / 2;
+        // Indirect lines cost region B's updates one more request each and save 7/8 of its memory: 8M-node graph, ms per
+        // 392 829 seeds: dense with the 2 560 slots that fit 536, indirect with all 3 072 slots 560-593; 4M: 269 against 303.
+        // So dense as long as it leaves ten wavefronts per CU, indirect beyond (n > ~10 M on 288 GB).
+        if (c->l_MB > 0 && !c->l_ind && env_int("ARCTE_HIP_B_INDIRECT", -1) < 0 && slots < std::min<int64_t>(asked, 10 * (int64_t)c->cus)) {
+            c->l_ind = 1;
+            slots = asked;
+            decide_spread();
+            while (slots > c->cus && (size_t)slots * lines_bytes_per_slot(c, qcap, pcap, scap) > budget) slots -= c->cus / 2;
+        }
+    }
     slots = std::max<int64_t>(1, slots);
     c->l_waves_per_cu = (int)std::max<int64_t>(1, std::min<int64_t>(32, (slots + c->cus - 1) / c->cus));
     int r = (c->l_spread && env_int("ARCTE_HIP_TEST_SPREAD_FAILS", 0)) ? fail(ARCTE_HIP_EHIP, "test hook: no room for spread slots")
@@ -1821,7 +1866,7 @@ static int run_seeds_impl(arcte_hip_ctx *c, const int64_t *seeds, int64_t nseeds
 
         // finished seeds of this launch: their rows are appended to rows_final in caller (position) order
         next.clear();
-        bool queue_over = false, out_over = false, contrib_over = false, pushed_over = false, sup_over = false;
+        bool queue_over = false, out_over = false, contrib_over = false, pushed_over = false, sup_over = false, pool_over = false;
         int64_t add = 0;
         std::vector<int32_t> by_pos(work);
         std::sort(by_pos.begin(), by_pos.end());
@@ -1844,13 +1889,14 @@ static int run_seeds_impl(arcte_hip_ctx *c, const int64_t *seeds, int64_t nseeds
                 contrib_over |= (st == ST_CONTRIB_OVERFLOW);
                 pushed_over |= (st == ST_PUSHED_OVERFLOW);
                 sup_over |= (st == ST_SUP_OVERFLOW);
+                pool_over |= (st == ST_POOL_OVERFLOW);
                 next.push_back(pos);
             }
         }
         if (mode == 2 && !next.empty()) {
             if (contrib_over) return RC_CONTRIB_FULL;
-            if (use_lines && (queue_over || pushed_over || sup_over)) {
-                r = grow_lines(c, queue_over, pushed_over, sup_over);
+            if (use_lines && (queue_over || pushed_over || sup_over || pool_over)) {
+                r = grow_lines(c, queue_over, pushed_over, sup_over, pool_over);
                 if (r) return r;
             } else if (queue_over) {
                 r = grow_queue(c);
@@ -1890,8 +1936,8 @@ static int run_seeds_impl(arcte_hip_ctx *c, const int64_t *seeds, int64_t nseeds
         }
         if (!next.empty()) {
             c->stats[4] += (int64_t)next.size();
-            if (use_lines && (queue_over || pushed_over || sup_over)) {
-                r = grow_lines(c, queue_over, pushed_over, sup_over);
+            if (use_lines && (queue_over || pushed_over || sup_over || pool_over)) {
+                r = grow_lines(c, queue_over, pushed_over, sup_over, pool_over);
                 if (r) return r;
             } else if (queue_over) {
                 r = grow_queue(c);

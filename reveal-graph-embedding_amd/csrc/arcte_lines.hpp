@@ -39,6 +39,7 @@ namespace {
 
 constexpr int32_t ST_PUSHED_OVERFLOW = 6;   // more distinct pushed nodes than PS holds: re-run with a larger one
 constexpr int32_t ST_SUP_OVERFLOW = 7;      // more candidates than the list holds
+constexpr int32_t ST_POOL_OVERFLOW = 8;     // more touched lines of region B than its pool holds (indirect lines)
 
 struct LineParams {
     const uint32_t *edge_rank;    // [nnz] rank of every stored edge's target (CSR order = FIFO order is kept)
@@ -53,6 +54,12 @@ struct LineParams {
     uint32_t M, Mshift;           // region A: lines per slot whose touched-bits are in LDS (power of two), log2; ranks < 8 M
     uint32_t MB, MBshift;         // region B (TAIL): lines for the ranks >= 8 M, touched-bits in gbm (0: every rank is in A)
     uint32_t *gbm;                // [slots][MB / 32]
+    // indirect region B (template flag IND): a line of region B lives in the next free line of a per-slot POOL (vals_b), its
+    // place is kept in bidx[line] = seed generation << 32 | pool line; bgen[slot] is the last generation the slot used
+    uint64_t *bidx;               // [slots][MB]
+    uint32_t *bgen;               // [slots]
+    uint32_t pool_cap;            // pool lines per slot
+    int64_t bidx_stride;
     // distance between two slots' parts of the arrays above, in elements of each: a slot's often touched parts (region A,
     // ring, candidates, pushed state, region B's bits) lie in ONE block whose size is a power of two, region B's values in
     // another (arcte_hip.hip: lines_layout)
@@ -93,16 +100,24 @@ __device__ __forceinline__ void blind_round(double *vals, double *vals_b, uint32
 // registers of the pipeline stages, LT 64-edge tiles per step (narrow rows: the weight is the row's, the in_degree a float)
 template <int LT, bool NARROW> struct LRowT { bool a[LT]; uint32_t v[LT]; double w[LT], d[LT]; };
 template <int LT> struct LRowT<LT, true> { bool a[LT]; uint32_t v[LT]; float d[LT]; };
-template <int LT> struct LSlotT { double x[LT]; bool owner[LT]; };
+template <int LT> struct LSlotT { double x[LT]; bool owner[LT]; uint32_t ix[LT]; };
 template <int LT> struct LPushedT { double2 q[LT]; };
-template <int LT> struct LClaimT { uint32_t old[LT]; };
+template <int LT> struct LClaimT { uint32_t old[LT]; uint64_t bi[LT]; };
 
 // TAIL: the graph has more ranks than the LDS bitmap covers (8 M); the others' lines have their touched-bits in a
 // per-slot bitmap in global memory (L2-resident for graphs of a few million nodes), claimed by a returning atomic OR one
 // pipeline stage before the line is written or read.
-template <int MODE, int VAR, bool NARROW, bool TAIL, bool PROF = false, int LT = 1, int WPE = 1, bool STAGE = false>
+// IND (with TAIL): region B's lines are INDIRECT.  Region B is as large as the graph (8 bytes per node and slot) but a seed
+// touches a few thousand of its lines, so a line that is claimed for the first time takes the next line of a small per-slot
+// pool (a wavefront-private counter: ballot + mbcnt), its owner stores `generation << 32 | pool line` in bidx[line] and
+// writes the pool line blind; later touches read bidx[line] -- ahead of time, with the claim: the entry is valid when its
+// generation is this seed's, which fails only for a line claimed by another lane of the same 64-edge step (then the entry
+// is read again after the owner's store) -- and then the value.  4 MB of bidx per million nodes + the pool instead of
+// 8 MB of values per million nodes; region A, the LDS level and the order of every floating-point operation are unchanged.
+template <int MODE, int VAR, bool NARROW, bool TAIL, bool PROF = false, int LT = 1, int WPE = 1, bool STAGE = false, bool IND = false>
 __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(WPE))) void k_arcte_lines(PushParams P, LineParams L)
 {
+    static_assert(!IND || (TAIL && !STAGE), "indirect lines are region B's");
     typedef LRowT<LT, NARROW> LRow;
     typedef LSlotT<LT> LSlot;
     typedef LPushedT<LT> LPushed;
@@ -129,6 +144,10 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(WPE))) voi
     double *__restrict__ vals = L.vals + slot * L.vals_stride;
     double *__restrict__ vals_b = L.vals_b + slot * L.valsb_stride;
     uint32_t *__restrict__ gbm = L.gbm + slot * L.gbm_stride;
+    uint64_t *__restrict__ bidx = IND ? L.bidx + slot * L.bidx_stride : nullptr;
+    uint32_t gen = 0;                                // IND: generation of the seed in hand (bidx entries of other seeds are stale)
+    if (IND) gen = L.bgen[slot];
+    uint32_t npool = 0;                              // IND: pool lines taken by the seed in hand
     double2 *__restrict__ ps = L.ps + slot * L.ps_stride;
     int32_t *__restrict__ sup = L.sup + slot * L.sup_stride;
     QEntry *__restrict__ q = P.queue + slot * L.q_stride;
@@ -143,7 +162,11 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(WPE))) voi
     };
     auto in_b = [&](uint32_t rk) -> bool { return TAIL && rk >= RA; };
     auto value_index = [&](uint32_t rk) -> uint32_t {
-        if (in_b(rk)) { const uint32_t rp = rk - RA; return RA + (((rp & MBmask) << 3) | (rp >> MBshift)); }
+        if (in_b(rk)) {
+            const uint32_t rp = rk - RA;
+            if constexpr (IND) return RA + (((uint32_t)bidx[rp & MBmask] << 3) | (rp >> MBshift));      // (of a line this seed has claimed)
+            else return RA + (((rp & MBmask) << 3) | (rp >> MBshift));
+        }
         return ((rk & Mmask) << 3) | (rk >> Mshift);
     };
     auto val_at = [&](uint32_t ix) -> double * { return (ix < RA ? vals : vals_b) + ix; };     // ix = line * 8 + place; region B's lines follow A's
@@ -196,6 +219,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(WPE))) voi
             }
         }
 
+        if (IND) { gen++; npool = 0; }
         uint32_t head = 0, tail = 0;
         int32_t nsup = 0, nfirst = 0;
         double cand_thr = 0.0;
@@ -228,9 +252,11 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(WPE))) voi
 #pragma unroll
                 for (int t = 0; t < LT; t++) {
                     C.old[t] = 0;
+                    C.bi[t] = 0;
                     if (TAIL && R.a[t] && R.v[t] >= RA) {
                         const uint32_t ln = (R.v[t] - RA) & MBmask;
                         C.old[t] = atomicOr(&gbm[ln >> 5], 1u << (ln & 31));
+                        if constexpr (IND) C.bi[t] = bidx[ln];          // (valid if the line was claimed in an earlier step)
                     }
                 }
             };
@@ -252,7 +278,31 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(WPE))) voi
                         owner = !(old & bit);
                     }
                     E.owner[t] = owner;
-                    const uint32_t index = value_index(rk);
+                    uint32_t index;
+                    if constexpr (IND) {
+                        const bool isb = line_lvl && rk >= RA;
+                        const uint32_t rp = rk - RA, ln = rp & MBmask;
+                        const uint64_t mo = __ballot(isb && owner);
+                        uint32_t pl = (uint32_t)C.bi[t];
+                        if (isb && owner) {
+                            pl = npool + lane_below(mo);
+                            if (pl >= L.pool_cap) pl = L.pool_cap - 1;          // (the seed fails below; nothing may be written outside)
+                            bidx[ln] = ((uint64_t)gen << 32) | pl;
+                        }
+                        npool += (uint32_t)__popcll(mo);
+                        if (npool > L.pool_cap) { ok = false; fail_status = ST_POOL_OVERFLOW; }
+                        // a line claimed by another lane of this very step: the entry read ahead is a stale one
+                        const bool again = isb && !owner && (uint32_t)(C.bi[t] >> 32) != gen;
+                        if (__ballot(again)) {
+                            __builtin_amdgcn_s_waitcnt(0x0F70);
+                            if (again) pl = (uint32_t)bidx[ln];
+                            __builtin_amdgcn_s_waitcnt(0x0F70);
+                        }
+                        index = isb ? RA + ((pl << 3) | (rp >> MBshift)) : (((rk & Mmask) << 3) | (rk >> Mshift));
+                        E.ix[t] = index;
+                    } else {
+                        index = value_index(rk);
+                    }
                     {
                         double wt;
                         if constexpr (NARROW) wt = w_row; else wt = R.w[t];
@@ -312,7 +362,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(WPE))) voi
                     if (act) {
                         if (mv) ps[moved_index(x)] = make_double2(r_new, s_new);
                         else if (rk < K) hot[rk] = r_new;
-                        else if (!E.owner[t]) *val_at(value_index(rk)) = r_new;
+                        else if (!E.owner[t]) *val_at(IND ? E.ix[t] : value_index(rk)) = r_new;
                     }
                     s_moved += __popcll(__ballot(mv));
                     s_lds += __popcll(__ballot(act && !mv && rk < K));
@@ -506,7 +556,11 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(WPE))) voi
             ps[0] = make_double2(1.0, (VAR == 0) ? 1.0 : 0.0);          // similarity.py:176-177 / :26 / :85
             if (sr < K) hot[sr] = moved_to(0);
             else {
-                if (in_b(sr)) { const uint32_t ln = (sr - RA) & MBmask; gbm[ln >> 5] |= 1u << (ln & 31); }
+                if (in_b(sr)) {
+                    const uint32_t ln = (sr - RA) & MBmask;
+                    gbm[ln >> 5] |= 1u << (ln & 31);
+                    if constexpr (IND) bidx[ln] = (uint64_t)gen << 32;          // pool line 0
+                }
                 else { const uint32_t ln = sr & Mmask; bm[ln >> 5] |= 1u << (ln & 31); }
                 const uint32_t ix = value_index(sr), sl = ix & 7u;
                 double2 *line = reinterpret_cast<double2 *>(val_at(ix & ~7u));
@@ -517,6 +571,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(WPE))) voi
             if (VAR == 0) sup[0] = (int32_t)sr;
         }
         npushed = 1;
+        if (IND && in_b(sr)) npool = 1;
         nsup = (VAR == 0) ? 1 : 0;
         nfirst = (VAR == 0) ? 1 : 0;
         if (MODE == 0 && VAR == 0) {
@@ -728,6 +783,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(WPE))) voi
 #pragma unroll
         for (int k = 0; k < 10; k++) atomicAdd(P.prof + k, prof[k]);
     }
+    if (IND && lane == 0) L.bgen[slot] = gen;
     if (lane == 0 && L.lstats) {
         atomicAdd(L.lstats + 0, c_lds);
         atomicAdd(L.lstats + 1, c_blind);

@@ -214,3 +214,56 @@ def test_spread_slots_fall_back_to_packed_ones(monkeypatch):
         assert np.array_equal(sorted_rows(colptr, rows), o_rows)
     finally:
         _native.trim()
+
+
+@pytest.mark.parametrize("name", ["ba300", "weighted", "selfloop", "directed", "rmat2000", "ws1000", "ba1500"])
+@pytest.mark.parametrize("variant", FLAVOURS)
+def test_indirect_region_b_matches_the_oracle(name, variant, monkeypatch):
+    """Region B's lines INDIRECT (arcte_lines.hpp, IND: an 8-byte entry per line + a pool of lines instead of eight float64 per
+    line; the default from 16 MB of region B per slot, forced here): same communities, push counts and work counters."""
+    g = load_golden(name)
+    o_colptr, o_rows, _, o_nop, o_stats = oracle.worker(g["w"], g["out_degree"], g["in_degree"], g["all_seeds"], g["rho"],
+                                                        g["epsilon"], want_stats=True, variant=variant)
+    monkeypatch.setenv("ARCTE_HIP_B_INDIRECT", "1")
+    for hot, lines_lds, poison in ((0, 64, None), (4, 64, 255), (24, 128, 165)):
+        if poison is None:
+            monkeypatch.delenv("ARCTE_HIP_POISON", raising=False)
+        else:
+            monkeypatch.setenv("ARCTE_HIP_POISON", str(poison))
+        colptr, rows, nop, st, info = run(g, hot, lines_lds, variant, monkeypatch)
+        tag = "%d on-chip values, %s lines in LDS, poison %s" % (hot, lines_lds, poison)
+        if g["n"] > 8 * lines_lds:
+            assert info["lines_region_b"] > 0, tag
+        assert np.array_equal(colptr, o_colptr), tag
+        assert np.array_equal(nop, o_nop), tag
+        assert np.array_equal(sorted_rows(colptr, rows), o_rows), tag
+        assert [st["pushes"], st["edges"], st["enqueues"], st["support"]] == list(o_stats), tag
+
+
+def test_indirect_region_b_pool_grows(monkeypatch):
+    """A pool that is too small flags the seed; the host makes it four times as large and runs the seed again."""
+    g = load_golden("rmat2000")
+    o_colptr, o_rows, _, o_nop, _ = oracle.worker(g["w"], g["out_degree"], g["in_degree"], g["all_seeds"], g["rho"], g["epsilon"],
+                                                  want_stats=True)
+    monkeypatch.setenv("ARCTE_HIP_B_INDIRECT", "1")
+    monkeypatch.setenv("ARCTE_HIP_B_POOL", "64")
+    colptr, rows, nop, st, info = run(g, 0, 64, oracle.ARCTE, monkeypatch)
+    assert st["reruns"] > 0 and st["launches"] > 1
+    assert np.array_equal(colptr, o_colptr) and np.array_equal(nop, o_nop)
+    assert np.array_equal(sorted_rows(colptr, rows), o_rows)
+
+
+@pytest.mark.parametrize("name", ["rmat2000", "ws1000"])
+def test_indirect_region_b_centrality(name, monkeypatch):
+    """arcte_and_centrality's seed loop through indirect lines: the reference's own vector, bit for bit."""
+    from reveal_graph_embedding_amd import _native
+    from test_centrality_weighting_cpu import load_centrality
+    g = load_centrality(name)
+    a = g["adjacency"]
+    monkeypatch.setenv("ARCTE_HIP_B_INDIRECT", "1")
+    monkeypatch.setenv("ARCTE_HIP_HOT", "0")
+    monkeypatch.setenv("ARCTE_HIP_LINES_LDS", "64")
+    with _native.Context.from_adjacency(a.indptr, a.indices, a.data) as ctx:
+        assert ctx.state_info()["lines_region_b"] > 0
+        ctx.run_centrality(float(g["rho"]), float(g["epsilon"]))
+        np.testing.assert_array_equal(ctx.centrality(), g["centrality"])
