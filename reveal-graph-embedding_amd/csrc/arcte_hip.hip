@@ -579,7 +579,9 @@ int draw_slot_memory(arcte_hip_ctx *c, size_t slots, size_t block)
             c->placement_probe.push_back(rate);
             if (best < 0 || rate > c->placement_probe[(size_t)best]) best = t;
             const double slowest = *std::min_element(c->placement_probe.begin(), c->placement_probe.end());
-            if (c->placement_probe[(size_t)best] >= 1.1 * slowest) break;          // both classes seen, a fast one in hand
+            // (packed slots: two classes, 20 and 24 -- a fast one in hand is enough; spread slots have a top level at 26 that a
+            //  20 / 24 pair does not show yet)
+            if (c->placement_probe[(size_t)best] >= (c->l_spread ? 1.25 : 1.1) * slowest) break;
             if (known_best > 0.0 && c->placement_probe[(size_t)best] >= 0.97 * known_best) break;   // as good as this process has seen
         }
         if (best < 0) return fail(ARCTE_HIP_EHIP, "no memory for the propagation slots");
