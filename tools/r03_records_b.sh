@@ -9,6 +9,7 @@ python bench.py --variant pagerank --steps 3 --cpu-seconds 0 > $O/bench_variant_
 python bench.py --variant lazy --steps 3 --cpu-seconds 0 > $O/bench_variant_lazy_pagerank.json 2>/dev/null; echo "lazy $?"
 python bench.py --nodes 4000000 --edges 100000000 --steps 2 --cpu-seconds 0 > $O/bench_n4M_m100M.json 2>/dev/null; echo "4M $?"
 python bench.py --nodes 8000000 --edges 100000000 --steps 2 --cpu-seconds 0 > $O/bench_n8M_m100M.json 2>/dev/null; echo "8M $?"
+python bench.py --nodes 16000000 --edges 200000000 --shards 16 --steps 2 --cpu-seconds 0 > $O/bench_n16M_m200M_every_16th_seed.json 2>/dev/null; echo "16M $?"
 python tools/e2e_time.py 1000000 50000000 > $O/e2e_arcte_1m.txt 2>&1; echo "e2e $?"
 python tools/e2e_time.py 100000 2000000 > $O/e2e_arcte_config1.txt 2>&1
 python tools/cli_time.py 100000 2000000 3 > $O/cli_time_config1.txt 2>&1; echo "cli $?"
