@@ -564,9 +564,12 @@ int draw_slot_memory(arcte_hip_ctx *c, size_t slots, size_t block)
             }
             const auto ta = std::chrono::steady_clock::now();
             if (cand[(size_t)t].alloc(bytes, c->device) != hipSuccess) { (void)hipGetLastError(); cand[(size_t)t].release(c->device); break; }
+            const double alloc_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - ta).count();
             if (env_int("ARCTE_HIP_VERBOSE", 0))
-                fprintf(stderr, "[arcte_hip] slot memory candidate %d: %.1f GB allocated in %.3f s\n", t, bytes / 1e9,
-                        std::chrono::duration<double>(std::chrono::steady_clock::now() - ta).count());
+                fprintf(stderr, "[arcte_hip] slot memory candidate %d: %.1f GB allocated in %.3f s\n", t, bytes / 1e9, alloc_s);
+            // (on some boxes a large hipMalloc that follows frees takes seconds -- profiles/r03/first_call_1m.txt: a draw is
+            //  worth a few per cent of the kernel's time, so this candidate is the last one)
+            if (alloc_s > 0.5) tries = t + 1;
             float ms = 0;
             for (int rep = 0; rep < 2; rep++) {          // (the first pass faults the translations in)
                 HIP_TRY(hipEventRecord(e0, c->stream));
