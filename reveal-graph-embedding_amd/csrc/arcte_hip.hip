@@ -567,9 +567,9 @@ int draw_slot_memory(arcte_hip_ctx *c, size_t slots, size_t block)
             const double alloc_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - ta).count();
             if (env_int("ARCTE_HIP_VERBOSE", 0))
                 fprintf(stderr, "[arcte_hip] slot memory candidate %d: %.1f GB allocated in %.3f s\n", t, bytes / 1e9, alloc_s);
-            // (on some boxes a large hipMalloc that follows frees takes seconds -- profiles/r03/first_call_1m.txt: a draw is
-            //  worth a few per cent of the kernel's time, so this candidate is the last one)
-            if (alloc_s > 0.5) tries = t + 1;
+            // (on some boxes a large hipMalloc that follows frees takes seconds -- profiles/r03/first_call_1m.txt; the draw goes on
+            //  all the same: ending it there left the first call of arcte() as slow as before -- the output buffers' allocations
+            //  are as slow -- and the context without its protection against the slow level)
             float ms = 0;
             for (int rep = 0; rep < 2; rep++) {          // (the first pass faults the translations in)
                 HIP_TRY(hipEventRecord(e0, c->stream));
