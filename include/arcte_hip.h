@@ -234,6 +234,19 @@ int arcte_hip_similarity_slice_variant(arcte_hip_ctx *ctx, int64_t seed, double 
                                        double *s, double *r, int64_t *nop);
 
 /*
+ * The same vectors out of the PRODUCTION kernel (k_arcte_lines, what arcte_hip_run_seeds launches): ONE seed runs
+ * through the worker loop as in arcte_hip_run_seeds_variant and, when its FIFO has run dry, the kernel gathers the
+ * seed's state from every level it lives on (on-chip values, the strided lines of regions A and B, the pushed-state
+ * array) into dense s[n] and r[n] by node id, starting from zeros as arcte_worker does (arcte.py:337-338): what
+ * fast_approximate_cumulative_pagerank_difference (similarity.py:149-222; variants: :11-146) leaves with its caller.
+ * use_effective_epsilon as in arcte_hip_run_seeds.  nop (may be NULL) receives the number of pushes.  A debug / parity
+ * entry: the run's result (one column) can be fetched afterwards like any other run's.  ARCTE_HIP_ESTATE when the
+ * context runs the dense-state kernel.
+ */
+int arcte_hip_seed_state(arcte_hip_ctx *ctx, int64_t seed, double rho, double epsilon, int use_effective_epsilon,
+                         int variant, double laziness_factor, double *s, double *r, int64_t *nop);
+
+/*
  * cumulative_pagerank_difference_limit_push (eps_randomwalk/push.py:41-64): one push of
  * `push_node` over (w_i, a_i) on caller-owned dense s[n], r[n].  Context-free.
  */

@@ -52,6 +52,8 @@ SIGNATURES = {
                                              C.POINTER(C.c_int64)]),
     "arcte_hip_similarity_slice_variant": (C.c_int, [C.c_void_p, C.c_int64, C.c_double, C.c_double, C.c_int, C.c_double,
                                                      _f64p, _f64p, C.POINTER(C.c_int64)]),
+    "arcte_hip_seed_state": (C.c_int, [C.c_void_p, C.c_int64, C.c_double, C.c_double, C.c_int, C.c_int, C.c_double, _f64p, _f64p,
+                                       C.POINTER(C.c_int64)]),
     "arcte_hip_push_variant": (C.c_int, [C.c_int, C.c_int64, _f64p, _f64p, _f64p, _i32p, C.c_int64, C.c_int64, C.c_double,
                                          C.c_int, C.c_double]),
     "arcte_hip_push": (C.c_int, [C.c_int, C.c_int64, _f64p, _f64p, _f64p, _i32p, C.c_int64, C.c_int64, C.c_double]),
@@ -438,6 +440,16 @@ class Context:
         _check(lib().arcte_hip_similarity_slice_variant(self._h, int(seed), float(rho), float(epsilon), int(variant),
                                                         float(laziness_factor), s, r, C.byref(nop)))
         return nop.value
+
+    def seed_state(self, seed, rho, epsilon, effective=False, variant=ARCTE, laziness_factor=0.5):
+        """ONE seed through the production kernel (k_arcte_lines); returns (s, r, nop): the dense float64 vectors of
+        similarity.py:149-222 gathered from every level of the kernel's state, starting from zeros."""
+        s = np.zeros(self.n, dtype=np.float64)
+        r = np.zeros(self.n, dtype=np.float64)
+        nop = C.c_int64(0)
+        _check(lib().arcte_hip_seed_state(self._h, int(seed), float(rho), float(epsilon), 1 if effective else 0, int(variant),
+                                          float(laziness_factor), s, r, C.byref(nop)))
+        return s, r, nop.value
 
 
 class Features:

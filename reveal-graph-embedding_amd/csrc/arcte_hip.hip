@@ -300,6 +300,8 @@ struct arcte_hip_ctx {
     int64_t line_stats[4] = {0, 0, 0, 0};   // last run: LDS updates, blind line writes, read-modify-writes, updates of pushed nodes
     std::vector<double> placement_probe;    // G updates/s of every candidate allocation of the slot memory, in draw order
     int placement_kept = -1;
+    DevBuf<double> dump_s, dump_r;          // arcte_hip_seed_state: the one seed's dense s and r (LineParams::dump_s)
+    int dump_on = 0;
     // per-run
     int64_t run_nseeds = -1;
     DevBuf<int32_t> seeds_d, work_pos, out_cnt, status, nop_d;
@@ -754,6 +756,8 @@ int launch_lines(arcte_hip_ctx *c, PushParams P, int64_t nwork, int variant, int
     L.scap = c->l_scap;
     L.K = lines_hot_values(c);
     L.lstats = c->l_stats.p;
+    L.dump_s = c->dump_on ? c->dump_s.p : nullptr;
+    L.dump_r = c->dump_on ? c->dump_r.p : nullptr;
     P.queue = reinterpret_cast<QEntry *>(c->l_block.p + c->l_off_queue);
     P.qcap = c->l_qcap;
     const size_t lds = (size_t)L.K * sizeof(double) + c->l_M / 8 + (env_int("ARCTE_HIP_STAGE_ROWS", 0) ? 2560 : 0);
@@ -1312,7 +1316,7 @@ extern "C" __attribute__((visibility("hidden"))) int arcte_io_set_error(int code
 
 extern "C" {
 
-int arcte_hip_abi_version(void) { return 8; }
+int arcte_hip_abi_version(void) { return 9; }
 
 const char *arcte_hip_last_error(void) { return g_err.c_str(); }
 
@@ -1563,6 +1567,8 @@ int arcte_hip_destroy(arcte_hip_ctx *c)
     c->l_block.release(c->device);
     c->l_blockb.release(c->device);
     c->l_stats.release();
+    c->l_gen.release();
+    c->dump_s.release(); c->dump_r.release();
     c->edge_rank.release(); c->node_rank.release(); c->rowspan.release(); c->in_degree_r.release();
     c->state.release(); c->slot_epoch.release(); c->warm.release(); c->contrib_key.release(); c->contrib_val.release(); c->centrality.release(); c->ranked_ids.release(); c->node_hot.release(); c->edge_hot.release(); c->edge_in_degree.release(); c->data_f.release(); c->in_degree_f.release(); c->edge_in_degree_f.release(); c->queue.release(); c->hqueue.release(); c->prof.release(); c->sup.release();
     c->seeds_d.release(); c->work_pos.release(); c->out_cnt.release(); c->status.release(); c->nop_d.release();
@@ -2502,6 +2508,30 @@ int arcte_hip_similarity_slice_variant(arcte_hip_ctx *c, int64_t seed, double rh
                                        double laziness_factor, double *s, double *r, int64_t *nop)
 {
     return similarity_slice_impl(c, seed, rho, epsilon, variant, laziness_factor, s, r, nop);
+}
+
+int arcte_hip_seed_state(arcte_hip_ctx *c, int64_t seed, double rho, double epsilon, int use_effective_epsilon, int variant,
+                         double laziness_factor, double *s, double *r, int64_t *nop)
+{
+    if (!c || !s || !r) return fail(ARCTE_HIP_EINVAL, "bad argument");
+    if (seed < 0 || seed >= c->n) return fail(ARCTE_HIP_EINVAL, "seed id out of range");
+    if (!c->lines || c->float32) return fail(ARCTE_HIP_ESTATE, "this context does not run the line-state kernel (ARCTE_HIP_STATE=dense or float32)");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(c->dump_s.reserve((size_t)c->n));
+    HIP_TRY(c->dump_r.reserve((size_t)c->n));
+    // (a seed that outgrows a capacity is run again by run_seeds_impl: the last run's dump stands)
+    c->dump_on = 1;
+    const int rc = run_seeds_impl(c, &seed, 1, rho, epsilon, use_effective_epsilon, variant, laziness_factor);
+    c->dump_on = 0;
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(s, c->dump_s.p, (size_t)c->n * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(r, c->dump_r.p, (size_t)c->n * sizeof(double), hipMemcpyDeviceToHost));
+    if (nop) {
+        int32_t h = 0;
+        HIP_TRY(hipMemcpy(&h, c->nop_d.p, sizeof(h), hipMemcpyDeviceToHost));
+        *nop = h;
+    }
+    return 0;
 }
 
 static int push_impl(int device, int64_t n, double *s, double *r, const double *w_i, const int32_t *a_i, int64_t deg,

@@ -68,6 +68,9 @@ struct LineParams {
     uint32_t pcap, scap;
     uint32_t K;                   // values of the LDS level
     unsigned long long *lstats;   // [0] LDS updates [1] blind line writes [2] read-modify-writes [3] updates of pushed nodes
+    // debug entry arcte_hip_seed_state (one seed per launch): dense s[n] and r[n] by NODE id, gathered from every level of
+    // the state when the FIFO has run dry -- what similarity.py:149-222 leaves with its caller.  nullptr: nothing is dumped
+    double *dump_s, *dump_r;
 };
 
 __device__ __forceinline__ double moved_to(uint32_t j) { return __longlong_as_double((long long)(0x7FF8DEAD00000000ull | (uint64_t)j)); }
@@ -687,6 +690,18 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(WPE))) voi
             }
         }
 
+        if (L.dump_s) {
+            // arcte_hip_seed_state: on-chip values, lines of region A and B (0 where the seed touched nothing) and the
+            // pushed-state array, as the dense vectors of the reference
+            for (int64_t rk = lane; rk < g.n; rk += WAVE) {
+                const double x = raw_value((uint32_t)rk);
+                double rv = x, sv = (VAR == 0) ? x : 0.0;
+                if (moved_is(x)) { const double2 e = ps[moved_index(x)]; rv = e.x; sv = e.y; }
+                const int32_t v = L.ranked_ids[rk];
+                L.dump_r[v] = rv;
+                L.dump_s[v] = sv;
+            }
+        }
         if (PROF) { const unsigned long long t = tick(); prof[4] += t - t_mark; t_mark = t; }
         // ---- arcte.py:352-376: degree-normalise, threshold = min over the closed neighbourhood, select, emit
         auto s_of = [&](uint32_t rk) -> double {

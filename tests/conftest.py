@@ -51,6 +51,15 @@ def assert_same_sparse(a, b, values=True):
         assert np.array_equal(a.data, b.data)
 
 
+@pytest.fixture(scope="session")
+def rmat_1m():
+    """BASELINE.json configs[2]'s graph (R-MAT 1M nodes / 50M sampled edges), generated once per session."""
+    from reveal_graph_embedding_amd.synthetic import rmat_graph
+    adjacency = rmat_graph(1000000, 50000000, seed=0)
+    assert adjacency.nnz == 88123742
+    return adjacency
+
+
 @pytest.fixture(params=GOLDEN_GRAPHS)
 def golden(request):
     return load_golden(request.param)

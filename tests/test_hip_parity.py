@@ -236,11 +236,10 @@ def test_config1_rmat_all_seeds_matches_reference_hash():
     assert np.array_equal(np.frombuffer(h.digest(), dtype=np.uint8), z["sha256"])
 
 
-def test_full_size_1m_graph_properties_and_sampled_oracle_parity():
+def test_full_size_1m_graph_properties_and_sampled_oracle_parity(rmat_1m):
     """BASELINE.json configs[2] at full size (R-MAT 1M nodes / 50M sampled edges): size-independent
     properties on a seed shard plus exact agreement with the oracle on a random sample of it."""
-    adjacency = rmat_graph(1000000, 50000000, seed=0)
-    assert adjacency.nnz == 88123742
+    adjacency = rmat_1m
     w, od, idg = get_natural_random_walk_matrix(adjacency)
     from reveal_graph_embedding_amd.embedding.arcte.arcte import seed_nodes
     seeds = seed_nodes(adjacency)

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for name in names:
         assert hasattr(lib, name), name
     assert sorted(_native.SIGNATURES) == names
-    assert _native.lib().arcte_hip_abi_version() == 8
+    assert _native.lib().arcte_hip_abi_version() == 9
 
 
 def test_no_gpu_means_loud_failure_not_fallback():

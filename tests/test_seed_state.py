@@ -1,0 +1,115 @@
+"""VALUE-level parity of the PRODUCTION kernel (k_arcte_lines, what arcte_hip_run_seeds / arcte() / bench.py launch).
+
+arcte_hip_seed_state runs ONE seed through that kernel and gathers its s and r from every level the state lives on
+(on-chip values, strided lines of regions A and B -- dense or indirect --, the pushed-state array).  The vectors must
+equal, as raw float64 bits, what the reference's fast_approximate_cumulative_pagerank_difference
+(eps_randomwalk/similarity.py:149-222) and its PageRank siblings (:11-146) left in s and r when the fixtures were
+generated (tests/golden/make_golden*.py), for every split of the state and the three push flavours."""
+import numpy as np
+import pytest
+
+from conftest import GOLDEN_GRAPHS, load_golden
+from oracle import oracle
+from test_line_state import SPLITS
+from test_pagerank_variants import PAGERANK_GRAPHS, load as load_pagerank, rho_of
+
+pytestmark = pytest.mark.gpu
+
+# (on-chip values, lines with touched-bits in LDS, region B's lines indirect)
+STATE_SPLITS = [(h, l, 0) for h, l in SPLITS] + [(0, 64, 1), (4, 64, 1)]
+
+
+def set_split(monkeypatch, hot, lines_lds, indirect):
+    monkeypatch.setenv("ARCTE_HIP_HOT", str(hot))
+    monkeypatch.delenv("ARCTE_HIP_STATE", raising=False)
+    if lines_lds is None:
+        monkeypatch.delenv("ARCTE_HIP_LINES_LDS", raising=False)
+    else:
+        monkeypatch.setenv("ARCTE_HIP_LINES_LDS", str(lines_lds))
+    if indirect:
+        monkeypatch.setenv("ARCTE_HIP_B_INDIRECT", "1")
+    else:
+        monkeypatch.delenv("ARCTE_HIP_B_INDIRECT", raising=False)
+
+
+def check_vectors(s, r, fx, prefix, k, tag):
+    for vec, v in ((s, "s"), (r, "r")):
+        lo, hi = fx[prefix + v + "_ptr"][k], fx[prefix + v + "_ptr"][k + 1]
+        nz = np.nonzero(vec)[0]
+        assert np.array_equal(nz, fx[prefix + v + "_idx"][lo:hi]), (tag, v, "support")
+        # raw float64 equality (a NaN would fail it too)
+        assert np.array_equal(vec[nz].view(np.uint64), fx[prefix + v + "_val"][lo:hi].view(np.uint64)), (tag, v, "values")
+
+
+@pytest.mark.parametrize("name", GOLDEN_GRAPHS)
+def test_arcte_state_of_the_production_kernel_equals_the_reference_vectors(name, monkeypatch):
+    from reveal_graph_embedding_amd import _native
+    g = load_golden(name)
+    w = g["w"]
+    for hot, lines_lds, indirect in STATE_SPLITS:
+        set_split(monkeypatch, hot, lines_lds, indirect)
+        with _native.Context(w.indptr, w.indices, w.data, g["out_degree"], g["in_degree"]) as ctx:
+            info = ctx.state_info()
+            assert info["line_state"] == 1
+            if lines_lds is not None and g["n"] > 8 * lines_lds:
+                assert info["lines_region_b"] > 0
+            for k, seed in enumerate(g["seeds"]):
+                tag = "%s seed %d: %d on-chip values, %s lines in LDS, indirect %d" % (name, seed, hot, lines_lds, indirect)
+                # the effective epsilon of the FIXTURE (numpy's logarithms) handed over as is, then the raw epsilon
+                s, r, nop = ctx.seed_state(int(seed), g["rho"], float(g["eps_eff"][k]))
+                assert nop == g["nop"][k], tag
+                check_vectors(s, r, g, "", k, tag)
+                s, r, nop = ctx.seed_state(int(seed), g["rho"], g["epsilon"])
+                assert nop == g["raw_nop"][k], tag
+                check_vectors(s, r, g, "raw_", k, tag)
+            # the device's own effective epsilon (<= 2 ulp from numpy's, tests/test_hip_parity.py): same pushes, same vectors
+            seed = int(g["seeds"][0])
+            s, r, nop = ctx.seed_state(seed, g["rho"], g["epsilon"], effective=True)
+            assert nop == g["nop"][0]
+            check_vectors(s, r, g, "", 0, "effective epsilon computed on the device")
+
+
+@pytest.mark.parametrize("name", PAGERANK_GRAPHS)
+@pytest.mark.parametrize("tag,variant", [("pr", oracle.PAGERANK), ("lazy", oracle.LAZY_PAGERANK)])
+def test_pagerank_states_of_the_production_kernel_equal_the_reference_vectors(name, tag, variant, monkeypatch):
+    from reveal_graph_embedding_amd import _native
+    g, p = load_pagerank(name)
+    w = g["w"]
+    for hot, lines_lds, indirect in STATE_SPLITS:
+        set_split(monkeypatch, hot, lines_lds, indirect)
+        with _native.Context(w.indptr, w.indices, w.data, g["out_degree"], g["in_degree"]) as ctx:
+            for k, seed in enumerate(g["seeds"]):
+                s, r, nop = ctx.seed_state(int(seed), rho_of(tag, g, p), float(g["eps_eff"][k]), variant=variant, laziness_factor=0.5)
+                what = "%s %s seed %d: %d on-chip values, %s lines in LDS, indirect %d" % (name, tag, seed, hot, lines_lds, indirect)
+                assert nop == p[tag + "_nop"][k], what
+                check_vectors(s, r, p, tag + "_", k, what)
+
+
+def test_state_of_a_seed_equals_the_oracle_on_a_larger_graph(monkeypatch):
+    """The config-1 graph (R-MAT 100k / 2M), default split: a handful of seeds, s and r against the oracle bit for bit."""
+    from reveal_graph_embedding_amd import _native
+    from reveal_graph_embedding_amd.synthetic import rmat_graph
+    a = rmat_graph(100000, 2000000, seed=0)
+    with _native.Context.from_adjacency(a.indptr, a.indices, a.data) as ctx:
+        seeds = ctx.seed_list()
+        indptr, indices, data, od, idg = ctx.transition()
+        import scipy.sparse as sparse
+        w = sparse.csr_matrix((data, indices, indptr), shape=a.shape)
+        eps = ctx.epsilon_effective(seeds, 1e-5)
+        for k in (0, 1, 17, 4000, 30000, seeds.size - 1):
+            s, r, nop = ctx.seed_state(int(seeds[k]), 0.1, float(eps[k]))
+            so, ro = np.zeros(a.shape[0]), np.zeros(a.shape[0])
+            nop_o = oracle.similarity(w, idg, int(seeds[k]), 0.1, float(eps[k]), so, ro)
+            assert nop == nop_o
+            assert np.array_equal(s.view(np.uint64), so.view(np.uint64)) and np.array_equal(r.view(np.uint64), ro.view(np.uint64))
+
+
+def test_seed_state_refuses_the_dense_state_kernel(monkeypatch):
+    from reveal_graph_embedding_amd import _native
+    g = load_golden("ba300")
+    w = g["w"]
+    monkeypatch.setenv("ARCTE_HIP_STATE", "dense")
+    with _native.Context(w.indptr, w.indices, w.data, g["out_degree"], g["in_degree"]) as ctx:
+        with pytest.raises(_native.ArcteHipError) as e:
+            ctx.seed_state(int(g["seeds"][0]), g["rho"], g["epsilon"])
+        assert e.value.code == -4
