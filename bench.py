@@ -200,9 +200,12 @@ def main():
     info = ctx.info()
     state = ctx.state_info()
     placement_kept, placement_rates = ctx.placement_info()
-    mem_free, mem_total = torch.cuda.mem_get_info(dev)
-    log("[bench] rank %d: n=%d nnz=%d seeds=%d shard=%d slots=%d device_bytes=%.1f GB (device: %.1f of %.1f GB free)" % (
-        rank, args.nodes, nnz, seeds.size, shard.size, info["slots"], info["device_bytes"] / 1e9, mem_free / 1e9, mem_total / 1e9))
+    mem = _native.memory_info(gpu)
+    mem_free, mem_total = mem["free_bytes"], mem["total_bytes"]
+    log("[bench] rank %d: n=%d nnz=%d seeds=%d shard=%d slots=%d context %.1f GB + parked draw losers %.1f GB + cached %.1f GB "
+        "(device: %.1f of %.1f GB in use)" % (
+            rank, args.nodes, nnz, seeds.size, shard.size, info["slots"], info["device_bytes"] / 1e9, mem["parked_bytes"] / 1e9,
+            mem["cached_bytes"] / 1e9, (mem_total - mem_free) / 1e9, mem_total / 1e9))
 
     variant = {"arcte": _native.ARCTE, "pagerank": _native.PAGERANK, "lazy": _native.LAZY_PAGERANK}[args.variant]
     run_rho = (args.rho * 0.5) / (1 - 0.5 * args.rho) if args.variant == "lazy" else args.rho   # arcte.py:109
@@ -380,6 +383,11 @@ def main():
                 "state": {k: state[k] for k in ("line_state", "lines_per_slot", "pushed_capacity", "candidate_capacity", "slot_bytes",
                                                 "bitmap_lds_bytes", "lds_bytes_per_wave", "lines_region_b")},
                 "kernel_source_id": kernel_source_id(),
+                # what the process holds on the device once the context exists: the context's own buffers, the losers of the
+                # slot-memory draw that stay allocated (at most one) and buffers kept from destroyed contexts
+                "device_memory": {"context_bytes": info["device_bytes"], "parked_bytes": mem["parked_bytes"],
+                                  "cached_bytes": mem["cached_bytes"], "in_use_bytes_after_create": mem_total - mem_free,
+                                  "total_bytes": mem_total},
                 "placement_tries": len(placement_ms), "placement_calibration_ms": [round(x, 2) for x in placement_ms],
                 # the library's own draw of the slot memory at context creation (every caller gets it): G updates/s of the
                 # probe on each candidate allocation, and which one was kept
@@ -396,7 +404,11 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": ("k_arcte_lines<0, %d, %s>" % (variant, "true" if info["narrow_rows"] else "false")) if state["line_state"] else
+                # (the name rocprofv3 prints: MODE, VAR, NARROW, TAIL, PROF, LT, WPE, STAGE, IND)
+                "kernel": ("void (anonymous namespace)::k_arcte_lines<0, %d, %s, %s, false, 1, 1, false, %s>((anonymous namespace)::PushParams, "
+                           "(anonymous namespace)::LineParams)" % (variant, "true" if info["narrow_rows"] else "false",
+                                                                   "true" if state["lines_region_b"] else "false",
+                                                                   "true" if state["region_b_indirect"] else "false")) if state["line_state"] else
                           "k_arcte_seeds<0, %d, %s, %d, %s%s>" % (variant, "float" if args.float32 else "double", info["tiles"],
                                                                   "true" if info["hot_values_per_wave"] else "false",
                                                                   ", true" if info["narrow_rows"] and info["hot_values_per_wave"] else ""),

@@ -49,8 +49,10 @@ int arcte_hip_device_count(int *count);
  * (eps_randomwalk/transition.py:43-99) and what arcte_worker receives
  * (embedding/arcte/arcte.py:279-286): CSR (indptr[n+1], indices[nnz] ascending inside a
  * row, data[nnz]) of W = D_out^-1 A, weighted out_degree[n], in_degree[n].
- * A slot is the scratch of one wavefront (one seed in flight): n_slots = 0 picks 6 wavefronts per compute unit
- * (ARCTE_HIP_WAVES_PER_CU overrides), fewer when the dense per-slot state would not fit 3/4 of the free memory;
+ * A slot is the scratch of one wavefront (one seed in flight): n_slots = 0 picks 12 wavefronts per compute unit
+ * (ARCTE_HIP_WAVES_PER_CU overrides) of the LINE state (arcte_hip_state_info: 8 bytes per node and slot in strided
+ * 64-byte lines, a touched-line bitmap + the hottest nodes' values in LDS), fewer when the slot memory would take the
+ * device past 65 % full; ARCTE_HIP_STATE=dense selects the round-2 state (32-byte entries, 6 wavefronts per CU);
  * the CU's LDS is divided among its resident wavefronts for the hot table.  queue_capacity = 0 picks
  * min(2^20, max(4096, n/16 rounded up to a power of two)) ring entries (the FIFO of similarity.py:180 is
  * unbounded; an overflowing seed is re-run with a 4x larger ring, never dropped).  A row that stores the same
@@ -351,6 +353,17 @@ int arcte_hip_append_result(arcte_hip_ctx *ctx, const int64_t *seeds, const int6
  */
 int arcte_hip_stream_bandwidth(int device, int64_t bytes, double *read_gbps, double *copy_gbps);
 
+/* 1 when the library was built with `make AB=1`: the launch shapes that lost their A/B in rounds 2-3 (ARCTE_HIP_TILES=2/4,
+ * ARCTE_HIP_STAGE_ROWS, ARCTE_HIP_COOP helper wavefronts, more than twelve wavefronts per CU on the 128-VGPR build) and the
+ * instrumented instantiation (ARCTE_HIP_PROFILE) exist; 0 (the default build): those knobs are ignored. */
+int arcte_hip_has_ab_builds(void);
+
+/* Device memory this PROCESS holds outside any context (no counterpart in the reference): info[0] bytes of placement-draw
+ * losers kept allocated on `device` (at most ARCTE_HIP_PARK_MAX = 1 buffer per device; returned by arcte_hip_trim, by a draw
+ * of another shape, by a growing context and whenever an allocation fails), [1] bytes of destroyed contexts' large buffers
+ * kept for the next context of the same shape, [2] free and [3] total bytes of the device as the runtime reports them. */
+int arcte_hip_memory_info(int device, int64_t info[4]);
+
 /* Diagnostic: how many workgroups of the float64 ARCTE propagation kernel the runtime's occupancy query admits per
  * compute unit with the context's launch shape (the slot count assumes info[7] / info[4] of them). */
 int arcte_hip_launch_occupancy(arcte_hip_ctx *ctx, int *workgroups_per_cu);
@@ -371,8 +384,9 @@ int arcte_hip_info(arcte_hip_ctx *ctx, int64_t info[10]);
  * [5] bytes of LDS the bitmap takes per wavefront; [6] bytes of LDS a wavefront may claim; [7] lines per slot of region B
  * (the ranks beyond 8 M: touched-bits in a per-slot bitmap in global memory; 0 = every rank is covered by the LDS bitmap);
  * of the last run: [8] updates of on-chip values, [9] blind whole-line writes (first touch of a line),
- * [10] read-modify-writes of a line, [11] updates of pushed nodes. */
-int arcte_hip_state_info(arcte_hip_ctx *ctx, int64_t info[12]);
+ * [10] read-modify-writes of a line, [11] updates of pushed nodes; [12] 1 when region B's lines are indirect (an 8-byte
+ * entry per line + a pool of lines per slot), [13] pool lines per slot. */
+int arcte_hip_state_info(arcte_hip_ctx *ctx, int64_t info[14]);
 
 /* The draws of the slot memory's placement made when the context was created (no counterpart in the reference): the
  * propagation kernel's speed depends on how its per-seed state is laid over the physical memory, which hipMalloc leaves

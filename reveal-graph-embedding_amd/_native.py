@@ -68,6 +68,8 @@ SIGNATURES = {
     "arcte_hip_info": (C.c_int, [C.c_void_p, _i64p]),
     "arcte_hip_state_info": (C.c_int, [C.c_void_p, _i64p]),
     "arcte_hip_placement_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), _f64p, C.c_int, C.POINTER(C.c_int)]),
+    "arcte_hip_memory_info": (C.c_int, [C.c_int, _i64p]),
+    "arcte_hip_has_ab_builds": (C.c_int, []),
     "arcte_hip_launch_occupancy": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "arcte_hip_features_from_result": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
     "arcte_hip_features_upload": (C.c_int, [C.c_int, C.c_int64, C.c_int64, C.c_int64, _i64p, _i32p, _f64p, C.POINTER(C.c_void_p)]),
@@ -128,6 +130,18 @@ def device_count():
 def trim():
     """Return the slot buffers that destroyed contexts left in the library's cache to the driver."""
     _check(lib().arcte_hip_trim())
+
+
+def has_ab_builds():
+    """True when the library was built with `make AB=1` (the launch shapes that lost their A/B exist)."""
+    return bool(lib().arcte_hip_has_ab_builds())
+
+
+def memory_info(device=0):
+    """Device memory the library holds outside any context + the device's fill (arcte_hip_memory_info)."""
+    i = np.zeros(4, dtype=np.int64)
+    _check(lib().arcte_hip_memory_info(int(device), i))
+    return dict(parked_bytes=int(i[0]), cached_bytes=int(i[1]), free_bytes=int(i[2]), total_bytes=int(i[3]))
 
 
 def epsilon_effective_scalar(epsilon, seed_degree, neighbor_degrees, device=0):
@@ -205,13 +219,26 @@ def fastest_context(make, calibrate, tries=3):
             trim()
 
 
+def _ids32(a, n, nnz_limit, what):
+    """Node ids as the C ABI takes them (int32): the reference's shared path carries int64 indices (transition.py:82-87);
+    sizes beyond this library's limits are refused HERE, by name, instead of being wrapped by the cast."""
+    if n >= 2 ** 31:
+        raise ValueError("%d nodes: node ids are int32 in this library (n < 2^31)" % n)
+    a = np.asarray(a)
+    if a.size >= nnz_limit:
+        raise ValueError("%d stored entries in %s: this entry point takes fewer than 2^%d" % (a.size, what, int(np.log2(nnz_limit))))
+    if a.size and a.dtype.kind in "iu" and a.dtype.itemsize > 4 and (int(a.max()) >= 2 ** 31 or int(a.min()) < 0):
+        raise ValueError("%s holds ids outside [0, 2^31): node ids are int32 in this library" % what)
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
 class Context:
     """Device-resident transition matrix + propagation slots on one GPU."""
 
     def __init__(self, indptr, indices, data, out_degree, in_degree, device=0, n_slots=0, queue_capacity=0):
         self._h = None
         indptr = np.ascontiguousarray(indptr, dtype=np.int64)
-        indices = np.ascontiguousarray(indices, dtype=np.int32)
+        indices = _ids32(indices, int(np.asarray(out_degree).size), 2 ** 31, "indices")
         data = np.ascontiguousarray(data, dtype=np.float64)
         out_degree = np.ascontiguousarray(out_degree, dtype=np.float64)
         in_degree = np.ascontiguousarray(in_degree, dtype=np.float64)
@@ -236,7 +263,7 @@ class Context:
     def from_adjacency(cls, indptr, indices, data, device=0, n_slots=0, queue_capacity=0):
         """Context from the ADJACENCY matrix (CSR): W, the degree vectors and the seed list are made on the device."""
         indptr = np.ascontiguousarray(indptr, dtype=np.int64)
-        indices = np.ascontiguousarray(indices, dtype=np.int32)
+        indices = _ids32(indices, int(indptr.size - 1), 2 ** 31, "indices")
         data = np.ascontiguousarray(data, dtype=np.float64)
         if indices.size != data.size or indptr.size < 2:
             raise ValueError("inconsistent CSR array sizes")
@@ -248,8 +275,8 @@ class Context:
     @classmethod
     def from_coo(cls, n, row, col, val, symmetrise=False, device=0, n_slots=0, queue_capacity=0):
         """Context from edge-list triplets; symmetrise=True makes (A + A^T)/2 first (entry_points/arcte.py:70-71)."""
-        row = np.ascontiguousarray(row, dtype=np.int32)
-        col = np.ascontiguousarray(col, dtype=np.int32)
+        row = _ids32(row, int(n), 2 ** 30, "row")
+        col = _ids32(col, int(n), 2 ** 30, "col")
         val = np.ascontiguousarray(val, dtype=np.float64)
         if not (row.size == col.size == val.size):
             raise ValueError("row, col and val must have one entry per triplet")
@@ -411,12 +438,12 @@ class Context:
 
     def state_info(self):
         """Where the per-seed state lives and, of the last run, how its updates were served (arcte_hip_state_info)."""
-        i = np.zeros(12, dtype=np.int64)
+        i = np.zeros(14, dtype=np.int64)
         _check(lib().arcte_hip_state_info(self._h, i))
         return dict(line_state=int(i[0]), lines_per_slot=int(i[1]), pushed_capacity=int(i[2]), candidate_capacity=int(i[3]),
                     slot_bytes=int(i[4]), bitmap_lds_bytes=int(i[5]), lds_bytes_per_wave=int(i[6]), lines_region_b=int(i[7]),
                     lds_updates=int(i[8]), blind_line_writes=int(i[9]), line_read_modify_writes=int(i[10]),
-                    pushed_node_updates=int(i[11]))
+                    pushed_node_updates=int(i[11]), region_b_indirect=int(i[12]), region_b_pool_lines=int(i[13]))
 
     def placement_info(self):
         """The candidate allocations of the slot memory probed at creation: (index kept, [G updates/s per candidate])."""

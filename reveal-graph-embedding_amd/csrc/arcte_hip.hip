@@ -103,6 +103,15 @@ struct DevBuf {
     size_t bytes() const { return count * sizeof(T); }
 };
 
+// releases a temporary DevBuf when the scope is left early (HIP_TRY returns); a buffer that changed hands (p = nullptr)
+// is left alone
+template <typename T>
+struct ScopedRelease {
+    DevBuf<T> &b;
+    explicit ScopedRelease(DevBuf<T> &buf) : b(buf) {}
+    ~ScopedRelease() { b.release(); }
+};
+
 // The slot buffers are tens of GB.  hipFree of such a buffer is deferred by the runtime and the NEXT large hipMalloc
 // pays for it -- 1.7 to 6 s per allocation on the MI355X boxes (tools/alloc_time.hip) -- which would dominate a
 // second arcte() call in the same process.  So a context hands its big buffers to a small process-wide cache when it
@@ -132,6 +141,28 @@ bool free_parked_buffers()
     g_parked.clear();
     if (any && have_current) (void)hipSetDevice(current);        // (the caller's allocation goes on)
     return any;
+}
+
+// the parked buffers of one device: all of them, or (keep_bytes > 0) those of any other size -- a draw of another shape
+// has no use for them and they would sit on memory the new slots want
+void free_parked_on(int device, size_t keep_bytes = 0)
+{
+    std::lock_guard<std::mutex> lock(g_big_mutex);
+    for (size_t i = 0; i < g_parked.size();) {
+        if (g_parked[i].device == device && (keep_bytes == 0 || g_parked[i].bytes != keep_bytes)) {
+            (void)hipFree(g_parked[i].p);          // (callers have set the device)
+            g_parked.erase(g_parked.begin() + (long)i);
+        } else i++;
+    }
+}
+
+size_t parked_bytes_on(int device)
+{
+    std::lock_guard<std::mutex> lock(g_big_mutex);
+    size_t b = 0;
+    for (const auto &e : g_parked)
+        if (e.device == device) b += e.bytes;
+    return b;
 }
 constexpr size_t BIG_BUFFER = (size_t)256 << 20;
 
@@ -410,6 +441,16 @@ int env_int(const char *name, int fallback)
     return fallback;
 }
 
+// ARCTE_HIP_STAGE_ROWS=1 (A/B of round 3, no gain): exists in `make AB=1` builds only
+int stage_rows_on()
+{
+#ifdef ARCTE_HIP_AB_BUILDS
+    return env_int("ARCTE_HIP_STAGE_ROWS", 0) != 0;
+#else
+    return 0;
+#endif
+}
+
 // Values of the LDS-resident hot table per wavefront: the CU's LDS divided by the wavefronts resident on it
 // (1 KiB allocation granularity), never more than there are ranked nodes.  ARCTE_HIP_HOT=0 switches the table
 // off (A/B), any other number caps it.
@@ -433,15 +474,16 @@ uint32_t hot_values_per_wave(const arcte_hip_ctx *c, size_t value_bytes)
 }
 
 // ---- line state (arcte_lines.hpp) -----------------------------------------------------------------------------
-// bytes of this device parked in the process-wide buffer cache: hipMemGetInfo does not count them as free, but the
-// next allocation of this process takes them back (or frees them)
+// bytes of this device in the process-wide buffer cache (buffers of destroyed contexts): hipMemGetInfo does not count
+// them as free, but the next allocation of this process takes them back or frees them (alloc_cached).  Parked losers of
+// a placement draw are NOT in this number: they stay allocated, so whoever sizes slot memory must count them as used
+// (round-3 advisor: counted as free they let a re-allocation push the device past the fill level where the kernel falls
+// off an edge, profiles/r03/device_fill_8m.txt).
 size_t cached_bytes_on(int device)
 {
     std::lock_guard<std::mutex> lock(g_big_mutex);
     size_t b = 0;
     for (const auto &e : g_big_cache)
-        if (e.device == device) b += e.bytes;
-    for (const auto &e : g_parked)          // (returned as soon as an allocation fails)
         if (e.device == device) b += e.bytes;
     return b;
 }
@@ -461,7 +503,7 @@ uint32_t lines_hot_values(const arcte_hip_ctx *c)
 {
     const int cap = env_int("ARCTE_HIP_HOT", -1);
     if (cap == 0) return 0;
-    const size_t per_wave = lines_lds_per_wave(c), bitmap = c->l_M / 8 + (env_int("ARCTE_HIP_STAGE_ROWS", 0) ? 2560 : 0);
+    const size_t per_wave = lines_lds_per_wave(c), bitmap = c->l_M / 8 + (stage_rows_on() ? 2560 : 0);
     if (per_wave <= bitmap) return 0;
     uint64_t k = (per_wave - bitmap) / sizeof(double);
     k = std::min<uint64_t>(k, (uint64_t)c->n);
@@ -543,6 +585,11 @@ int draw_slot_memory(arcte_hip_ctx *c, size_t slots, size_t block)
         return 0;
     }
     if (c->l_spread) tries = std::min(tries, std::max(1, env_int("ARCTE_HIP_SPREAD_TRIES", 3)));      // (candidates of 50 GB and more)
+    free_parked_on(c->device, bytes);          // losers of a draw of another shape: of no use to this one
+    // A draw may cost this much allocation time before it settles for what it holds (on some boxes a hipMalloc of tens of
+    // GB takes a second or more, profiles/r03/first_call_1m.txt: there the third candidate is not worth its price)
+    const double alloc_budget_s = std::max(0, env_int("ARCTE_HIP_DRAW_ALLOC_MS", 1200)) * 1e-3;
+    double alloc_spent_s = 0.0;
     std::vector<SlotMem> cand((size_t)tries);
     DevBuf<unsigned long long> sink;
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -563,10 +610,12 @@ int draw_slot_memory(arcte_hip_ctx *c, size_t slots, size_t block)
                 size_t free_b = 0, total_b = 0;
                 HIP_TRY(hipMemGetInfo(&free_b, &total_b));
                 if (free_b + cached_bytes_on(c->device) < bytes + bytes / 2 + ((size_t)24 << 30)) break;      // no room for another candidate
+                if (alloc_spent_s > alloc_budget_s) break;
             }
             const auto ta = std::chrono::steady_clock::now();
             if (cand[(size_t)t].alloc(bytes, c->device) != hipSuccess) { (void)hipGetLastError(); cand[(size_t)t].release(c->device); break; }
             const double alloc_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - ta).count();
+            alloc_spent_s += alloc_s;
             if (env_int("ARCTE_HIP_VERBOSE", 0))
                 fprintf(stderr, "[arcte_hip] slot memory candidate %d: %.1f GB allocated in %.3f s\n", t, bytes / 1e9, alloc_s);
             // (on some boxes a large hipMalloc that follows frees takes seconds -- profiles/r03/first_call_1m.txt; the draw goes on
@@ -604,10 +653,22 @@ int draw_slot_memory(arcte_hip_ctx *c, size_t slots, size_t block)
     cand[(size_t)best].plain.p = nullptr;
     cand[(size_t)best].p = nullptr;
     {
-        // the losers are parked (see g_parked); the best rate is remembered for the next context of this shape
+        // Of the losers at most ARCTE_HIP_PARK_MAX (1) stay allocated per device -- the SLOWEST: the allocator cannot hand
+        // that memory out again and one deferred hipFree less is paid for by the next hipMalloc -- the others go back to the
+        // driver before the context exists (round 3 kept them all: 155 GB held for a 1M-node graph).  The best rate is
+        // remembered for the next context of this shape.
+        const int park_max = std::max(0, env_int("ARCTE_HIP_PARK_MAX", 1));
+        std::vector<std::pair<double, size_t>> losers;          // (probe rate, candidate)
+        for (size_t i = 0; i < cand.size(); i++)
+            if (cand[i].plain.p) losers.push_back({i < c->placement_probe.size() ? c->placement_probe[i] : 0.0, i});
+        std::sort(losers.begin(), losers.end());
         std::lock_guard<std::mutex> lock(g_big_mutex);
-        for (auto &m : cand) {
-            if (m.plain.p) g_parked.push_back({c->device, (void *)m.plain.p, m.plain.capacity});
+        int parked_here = 0;
+        for (const auto &e : g_parked) parked_here += e.device == c->device;
+        for (const auto &l : losers) {
+            SlotMem &m = cand[l.second];
+            if (parked_here < park_max) { g_parked.push_back({c->device, (void *)m.plain.p, m.plain.capacity}); parked_here++; }
+            else (void)hipFree(m.plain.p);
             m.plain.p = nullptr; m.plain.count = 0; m.plain.capacity = 0; m.p = nullptr; m.size = 0;
         }
         bool found = false;
@@ -615,7 +676,7 @@ int draw_slot_memory(arcte_hip_ctx *c, size_t slots, size_t block)
             if (b.device == c->device && b.bytes == bytes) { b.rate = std::max(b.rate, c->placement_probe[(size_t)best]); found = true; }
         if (!found) g_best_probe.push_back({c->device, bytes, c->placement_probe[(size_t)best]});
         if (env_int("ARCTE_HIP_VERBOSE", 0))
-            fprintf(stderr, "[arcte_hip] slot memory: %d candidates probed, kept %d, %d buffers parked\n", (int)c->placement_probe.size(), best, (int)g_parked.size());
+            fprintf(stderr, "[arcte_hip] slot memory: %d candidates probed, kept %d, %d buffer(s) parked on this device\n", (int)c->placement_probe.size(), best, parked_here);
     }
     c->placement_kept = best;
     return 0;
@@ -676,6 +737,9 @@ int grow_lines(arcte_hip_ctx *c, bool queue_over, bool pushed_over, bool sup_ove
         if (c->l_pool >= c->l_MB) return fail(ARCTE_HIP_ECAPACITY, "region B's pool already holds every line");
         c->l_pool = std::min<uint32_t>(c->l_MB, c->l_pool * 4);
     }
+    // (the slot memory changes its shape: losers of the old shape's draw are of no use any more, and left allocated they
+    //  would push the device's fill past what setup_lines budgeted for)
+    free_parked_on(c->device);
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
     free_b += c->slot_bytes_lines() + cached_bytes_on(c->device);
@@ -702,14 +766,16 @@ int launch_lines_v(arcte_hip_ctx *c, const PushParams &P, const LineParams &L, i
     // ARCTE_HIP_TILES=2 / 4 keep the longer steps for ARCTE's worker on narrow rows (A/B).
     if (tail && c->l_ind)          // region B's lines indirect
         return c->narrow ? go(k_arcte_lines<MODE, VAR, true, true, false, 1, 1, false, true>) : go(k_arcte_lines<MODE, VAR, false, true, false, 1, 1, false, true>);
+#ifdef ARCTE_HIP_AB_BUILDS          // the arms that lost their A/B (profiles/r03): `make AB=1` builds them, the knobs below select them
     if (c->narrow && c->tiles == 4 && MODE == 0 && VAR == 0) return tail ? go(k_arcte_lines<0, 0, true, true, false, 4>) : go(k_arcte_lines<0, 0, true, false, false, 4>);
     if (c->narrow && c->tiles == 2 && MODE == 0 && VAR == 0 && c->l_waves_per_cu > 8)   // two tiles at three wavefronts per SIMD (168 VGPRs)
         return tail ? go(k_arcte_lines<0, 0, true, true, false, 2, 3>) : go(k_arcte_lines<0, 0, true, false, false, 2, 3>);
     if (c->narrow && c->tiles == 2 && MODE == 0 && VAR == 0) return tail ? go(k_arcte_lines<0, 0, true, true, false, 2>) : go(k_arcte_lines<0, 0, true, false, false, 2>);
-    if (c->narrow && MODE == 0 && VAR == 0 && env_int("ARCTE_HIP_STAGE_ROWS", 0))       // A/B: row data of the steps in flight staged through LDS
+    if (c->narrow && MODE == 0 && VAR == 0 && stage_rows_on())       // A/B: row data of the steps in flight staged through LDS
         return tail ? go(k_arcte_lines<0, 0, true, true, false, 1, 1, true>) : go(k_arcte_lines<0, 0, true, false, false, 1, 1, true>);
     if (c->narrow && MODE == 0 && VAR == 0 && c->l_waves_per_cu > 12)      // four wavefronts per SIMD: the compiler spills to fit 128 VGPRs
         return tail ? go(k_arcte_lines<0, 0, true, true, false, 1, 4>) : go(k_arcte_lines<0, 0, true, false, false, 1, 4>);
+#endif
     if (c->narrow) return tail ? go(k_arcte_lines<MODE, VAR, true, true, false, 1>) : go(k_arcte_lines<MODE, VAR, true, false, false, 1>);
     return tail ? go(k_arcte_lines<MODE, VAR, false, true, false, 1>) : go(k_arcte_lines<MODE, VAR, false, false, false, 1>);
 }
@@ -760,9 +826,10 @@ int launch_lines(arcte_hip_ctx *c, PushParams P, int64_t nwork, int variant, int
     L.dump_r = c->dump_on ? c->dump_r.p : nullptr;
     P.queue = reinterpret_cast<QEntry *>(c->l_block.p + c->l_off_queue);
     P.qcap = c->l_qcap;
-    const size_t lds = (size_t)L.K * sizeof(double) + c->l_M / 8 + (env_int("ARCTE_HIP_STAGE_ROWS", 0) ? 2560 : 0);
+    const size_t lds = (size_t)L.K * sizeof(double) + c->l_M / 8 + (stage_rows_on() ? 2560 : 0);
     const int blocks = (int)std::min<int64_t>(c->l_slots, std::max<int64_t>(nwork, 1));
     if (mode == 2) return launch_lines_v<2, 0>(c, P, L, blocks, lds);
+#ifdef ARCTE_HIP_AB_BUILDS          // ARCTE_HIP_PROFILE=1: the instrumented instantiation (tools/phase_profile.py)
     if (c->prof.p && c->narrow && variant == 0 && !c->l_ind) {
         auto kernel = c->l_MB > 0 ? k_arcte_lines<0, 0, true, true, true, 1> : k_arcte_lines<0, 0, true, false, true, 1>;
         if (lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -770,6 +837,7 @@ int launch_lines(arcte_hip_ctx *c, PushParams P, int64_t nwork, int variant, int
         HIP_TRY(hipGetLastError());
         return 0;
     }
+#endif
     if (variant == 1) return launch_lines_v<0, 1>(c, P, L, blocks, lds);
     if (variant == 2) return launch_lines_v<0, 2>(c, P, L, blocks, lds);
     return launch_lines_v<0, 0>(c, P, L, blocks, lds);
@@ -793,16 +861,17 @@ int launch_seeds_v(arcte_hip_ctx *c, PushParams P, int64_t nwork)
     P.warm = (void *)c->warm.p;
     P.warmK2 = c->warm_k2;
     P.warmN = (uint32_t)c->warm_n;
-    if (MODE == 1) {
+    if constexpr (MODE == 1) {
         // works on the dense vectors the host placed in slot 0: exactly one wavefront may run, all state in HBM
         return launch_with_lds(k_arcte_seeds<MODE, VAR, T, 2, false>, 1, WAVE, 0, c->stream, P);
-    }
+    } else {
     const int wpb = c->waves_per_block;
     const int64_t waves = std::min<int64_t>(c->slots, std::max<int64_t>(nwork, 1));
     const int blocks = (int)((waves + wpb - 1) / wpb);
     P.hotK = hot_values_per_wave(c, sizeof(T));
     const size_t lds = (size_t)wpb * P.hotK * sizeof(T);
     if (P.hotK == 0) return launch_with_lds(k_arcte_seeds<MODE, VAR, T, 2, false>, blocks, wpb * WAVE, lds, c->stream, P);
+#ifdef ARCTE_HIP_AB_BUILDS
     if constexpr (std::is_same<T, double>::value && MODE == 0 && VAR == 0) {
         if (c->prof.p && c->narrow && !c->coop && c->tiles == 2)
             return launch_with_lds(k_arcte_seeds<0, 0, double, 2, true, true, false, true>, blocks, wpb * WAVE, lds, c->stream, P);
@@ -814,12 +883,14 @@ int launch_seeds_v(arcte_hip_ctx *c, PushParams P, int64_t nwork)
             return launch_with_lds(k_arcte_seeds<0, 0, double, 2, true, false, true>, seeds_in_flight, 2 * WAVE, lds2, c->stream, P);
         }
     }
-    if constexpr (std::is_same<T, double>::value) {
+    if constexpr (std::is_same<T, double>::value)
         if (c->narrow && c->tiles == 4) return launch_with_lds(k_arcte_seeds<MODE, VAR, T, 4, true, true>, blocks, wpb * WAVE, lds, c->stream, P);
-        if (c->narrow) return launch_with_lds(k_arcte_seeds<MODE, VAR, T, 2, true, true>, blocks, wpb * WAVE, lds, c->stream, P);
-    }
     if (c->tiles == 4) return launch_with_lds(k_arcte_seeds<MODE, VAR, T, 4, true>, blocks, wpb * WAVE, lds, c->stream, P);
+#endif
+    if constexpr (std::is_same<T, double>::value)
+        if (c->narrow) return launch_with_lds(k_arcte_seeds<MODE, VAR, T, 2, true, true>, blocks, wpb * WAVE, lds, c->stream, P);
     return launch_with_lds(k_arcte_seeds<MODE, VAR, T, 2, true>, blocks, wpb * WAVE, lds, c->stream, P);
+    }
 }
 
 // MODE 2 exists for ARCTE's own push in float64 only (arcte.pyx has no other flavour)
@@ -1210,11 +1281,18 @@ int ctx_finish(arcte_hip_ctx *c, int64_t n_slots, int64_t queue_capacity)
     c->warm_k2 = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(env_int("ARCTE_HIP_WARM", 32768), c->hot_ranked));
     if (env_int("ARCTE_HIP_HOT", -1) == 0) c->warm_k2 = 0;
     c->waves_per_block = std::max(1, std::min(env_int("ARCTE_HIP_WAVES_PER_BLOCK", 1), WAVES_PER_BLOCK));
+#ifdef ARCTE_HIP_AB_BUILDS
     c->coop = env_int("ARCTE_HIP_COOP", 0) != 0 && env_int("ARCTE_HIP_HOT", -1) != 0;
+#else
+    c->coop = 0;          // (helper wavefronts, two / four tiles per step, staged rows, the profile: `make AB=1`)
+#endif
     c->coop_min = std::max(2 * 128, env_int("ARCTE_HIP_COOP_MIN", 512));
     if (c->coop) c->waves_per_block = 1;
     c->tiles = env_int("ARCTE_HIP_TILES", 1);
     if (c->tiles != 2 && c->tiles != 4) c->tiles = 1;
+#ifndef ARCTE_HIP_AB_BUILDS
+    c->tiles = 1;
+#endif
     c->want_slots = n_slots;
     c->want_queue = queue_capacity;
     // ---- which state?  Lines (arcte_lines.hpp) unless the dense state is asked for.  The LDS bitmap covers the
@@ -1573,7 +1651,9 @@ int arcte_hip_destroy(arcte_hip_ctx *c)
     c->state.release(); c->slot_epoch.release(); c->warm.release(); c->contrib_key.release(); c->contrib_val.release(); c->centrality.release(); c->ranked_ids.release(); c->node_hot.release(); c->edge_hot.release(); c->edge_in_degree.release(); c->data_f.release(); c->in_degree_f.release(); c->edge_in_degree_f.release(); c->queue.release(); c->hqueue.release(); c->prof.release(); c->sup.release();
     c->seeds_d.release(); c->work_pos.release(); c->out_cnt.release(); c->status.release(); c->nop_d.release();
     c->eps_d.release(); c->out_off.release(); c->dst_off.release(); c->counters.release();
-    c->raw.release(); c->rows_final.release(); c->sort_keys.release(); c->sort_iota.release(); c->sort_temp.release(); c->eps_big_pos.release(); c->sort_keys_in.release();
+    // (the output arena and the result rows are GBs: freed and allocated again by the next context's run they cost that run a
+    //  hipMalloc behind deferred frees -- 1.85 s against 0.90 in profiles/r03/first_call_1m.txt -- so they are cached like the slots)
+    release_cached(c->raw, c->device); release_cached(c->rows_final, c->device); c->sort_keys.release(); c->sort_iota.release(); c->sort_temp.release(); c->eps_big_pos.release(); c->sort_keys_in.release();
     for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -1744,7 +1824,7 @@ static int run_seeds_impl(arcte_hip_ctx *c, const int64_t *seeds, int64_t nseeds
 
     // raw arena: grows on demand (seeds that did not fit are re-run)
     if (c->raw.count < (size_t)c->n || c->raw_for_seeds < nseeds) {
-        c->raw.release();
+        release_cached(c->raw, c->device);
         c->raw_for_seeds = nseeds;
         size_t free_b = 0, total_b = 0;
         HIP_TRY(hipMemGetInfo(&free_b, &total_b));
@@ -1756,7 +1836,7 @@ static int run_seeds_impl(arcte_hip_ctx *c, const int64_t *seeds, int64_t nseeds
             long long v = atoll(env);
             if (v > 0) want = std::max<size_t>((size_t)c->n, (size_t)v);
         }
-        HIP_TRY(c->raw.alloc(want));
+        HIP_TRY(alloc_cached(c->raw, want, c->device));          // (a destroyed context of this shape left its arena in the cache)
     }
 
     if (use_effective_epsilon) {
@@ -1923,8 +2003,9 @@ static int run_seeds_impl(arcte_hip_ctx *c, const int64_t *seeds, int64_t nseeds
         if (add > 0) {
             if ((size_t)(final_used + add) > c->rows_final.count) {
                 DevBuf<int32_t> bigger;
+                ScopedRelease<int32_t> bigger_guard(bigger);
                 size_t want = std::max<size_t>((size_t)(final_used + add), c->rows_final.count * 2);
-                HIP_TRY(bigger.alloc(want));
+                HIP_TRY(alloc_cached(bigger, want, c->device));
                 if (final_used)
                     HIP_TRY(hipMemcpyAsync(bigger.p, c->rows_final.p, final_used * sizeof(int32_t), hipMemcpyDeviceToDevice, c->stream));
                 HIP_TRY(hipStreamSynchronize(c->stream));
@@ -2105,6 +2186,7 @@ int arcte_hip_run_centrality(arcte_hip_ctx *c, int64_t node_begin, int64_t node_
             if (c->final_rows) {
                 if ((size_t)(rows_used + c->final_rows) > all_rows.count) {
                     DevBuf<int32_t> bigger;
+                    ScopedRelease<int32_t> bigger_guard(bigger);
                     HIP_TRY(bigger.alloc(std::max<size_t>((size_t)(rows_used + c->final_rows), all_rows.count * 2)));
                     if (rows_used) HIP_TRY(hipMemcpyAsync(bigger.p, all_rows.p, rows_used * sizeof(int32_t), hipMemcpyDeviceToDevice, c->stream));
                     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -2347,6 +2429,7 @@ int arcte_hip_append_result(arcte_hip_ctx *c, const int64_t *seeds, const int64_
     // grow the two device arrays, keeping what they hold
     if ((size_t)(ns0 + nseeds) > c->seeds_d.capacity) {
         DevBuf<int32_t> bigger;
+        ScopedRelease<int32_t> bigger_guard(bigger);
         HIP_TRY(bigger.alloc(std::max<size_t>((size_t)(ns0 + nseeds), c->seeds_d.capacity * 2)));
         if (ns0) HIP_TRY(hipMemcpy(bigger.p, c->seeds_d.p, ns0 * sizeof(int32_t), hipMemcpyDeviceToDevice));
         c->seeds_d.release();
@@ -2356,6 +2439,7 @@ int arcte_hip_append_result(arcte_hip_ctx *c, const int64_t *seeds, const int64_
     c->seeds_d.count = (size_t)(ns0 + nseeds);
     if ((size_t)(rows0 + nrows) > c->rows_final.capacity) {
         DevBuf<int32_t> bigger;
+        ScopedRelease<int32_t> bigger_guard(bigger);
         HIP_TRY(bigger.alloc(std::max<size_t>((size_t)(rows0 + nrows), c->rows_final.capacity * 2)));
         if (rows0) HIP_TRY(hipMemcpy(bigger.p, c->rows_final.p, rows0 * sizeof(int32_t), hipMemcpyDeviceToDevice));
         c->rows_final.release();
@@ -2986,6 +3070,28 @@ int arcte_hip_trim(void)
     return 0;
 }
 
+int arcte_hip_has_ab_builds(void)
+{
+#ifdef ARCTE_HIP_AB_BUILDS
+    return 1;
+#else
+    return 0;
+#endif
+}
+
+int arcte_hip_memory_info(int device, int64_t info[4])
+{
+    if (!info) return fail(ARCTE_HIP_EINVAL, "bad argument");
+    HIP_TRY(hipSetDevice(device));
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    info[0] = (int64_t)parked_bytes_on(device);
+    info[1] = (int64_t)cached_bytes_on(device);
+    info[2] = (int64_t)free_b;
+    info[3] = (int64_t)total_b;
+    return 0;
+}
+
 int arcte_hip_set_float32(arcte_hip_ctx *c, int enable)
 {
     if (!c) return fail(ARCTE_HIP_EINVAL, "ctx is NULL");
@@ -3049,7 +3155,7 @@ int arcte_hip_info(arcte_hip_ctx *c, int64_t info[10])
     return 0;
 }
 
-int arcte_hip_state_info(arcte_hip_ctx *c, int64_t info[12])
+int arcte_hip_state_info(arcte_hip_ctx *c, int64_t info[14])
 {
     if (!c || !info) return fail(ARCTE_HIP_EINVAL, "bad argument");
     const bool lines = c->lines && !c->float32;
@@ -3062,6 +3168,8 @@ int arcte_hip_state_info(arcte_hip_ctx *c, int64_t info[12])
     info[6] = lines ? (int64_t)lines_lds_per_wave(c) : 0;
     info[7] = lines ? (int64_t)c->l_MB : 0;
     for (int i = 0; i < 4; i++) info[8 + i] = c->line_stats[i];
+    info[12] = (lines && c->l_ind) ? 1 : 0;
+    info[13] = (lines && c->l_ind) ? (int64_t)c->l_pool : 0;
     return 0;
 }
 

@@ -8,7 +8,11 @@ import pytest
 from conftest import load_golden
 from oracle import oracle
 
-pytestmark = pytest.mark.gpu
+from reveal_graph_embedding_amd import _native as _n
+
+# the helper-wavefront shape lost its A/B in round 2 (profiles/r02/ab_interleaved_4_helper_wavefront.txt) and is compiled by
+# `make AB=1` only
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not _n.has_ab_builds(), reason="library built without the A/B launch shapes (make AB=1)")]
 
 
 def hip(monkeypatch, w, out_degree, in_degree, seeds, rho, epsilon, coop, coop_min=256, hot=None, warm=None, **kw):

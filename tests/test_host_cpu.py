@@ -122,3 +122,19 @@ def test_fastest_context_keeps_the_best_draw_and_closes_the_rest():
     made_b = []
     best, results = _native.fastest_context(make_then_fail, lambda c: c.speed, tries=3)
     assert best is made_b[0] and results == [5.0] and not best.closed
+
+
+def test_sizes_beyond_int32_are_refused_by_name_before_the_cast():
+    """The reference's shared path carries int64 indices (transition.py:82-87); here node ids are int32.  An id that does not
+    fit must raise a ValueError naming the limit instead of being wrapped by the dtype cast."""
+    big = np.array([1, 2 ** 31 + 5], dtype=np.int64)
+    with pytest.raises(ValueError, match="int32"):
+        _native.Context.from_adjacency(np.array([0, 1, 2], dtype=np.int64), big, np.ones(2))
+    with pytest.raises(ValueError, match="int32"):
+        _native.Context.from_coo(2, big, np.array([0, 1]), np.ones(2))
+    with pytest.raises(ValueError, match="int32"):
+        _native.Context(np.array([0, 1, 2]), big, np.ones(2), np.ones(2), np.ones(2))
+    with pytest.raises(ValueError, match="2\\^31"):
+        _native._ids32(np.zeros(3, dtype=np.int64), 2 ** 31, 2 ** 31, "indices")
+    # what fits goes through to the library (which has no device here, or builds the context)
+    assert _native._ids32(np.array([0, 5], dtype=np.int64), 6, 2 ** 31, "indices").dtype == np.int32

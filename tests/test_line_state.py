@@ -267,3 +267,47 @@ def test_indirect_region_b_centrality(name, monkeypatch):
         assert ctx.state_info()["lines_region_b"] > 0
         ctx.run_centrality(float(g["rho"]), float(g["epsilon"]))
         np.testing.assert_array_equal(ctx.centrality(), g["centrality"])
+
+
+def test_at_most_one_draw_loser_stays_allocated(monkeypatch):
+    """Round-3 review / advisor: the placement draw kept EVERY loser allocated (155 GB for a 1M-node graph) and counted them
+    as free when it sized slot memory.  Now at most ARCTE_HIP_PARK_MAX (1) loser per device stays, losers of another shape
+    are returned before a draw and when a context's slot memory grows, and the library reports what it holds."""
+    from reveal_graph_embedding_amd import _native
+    g = load_golden("rmat2000")
+    w = g["w"]
+    o_colptr, o_rows, _, o_nop, _ = oracle.worker(w, g["out_degree"], g["in_degree"], g["all_seeds"], g["rho"], g["epsilon"], want_stats=True)
+    monkeypatch.setenv("ARCTE_HIP_PLACEMENT_MIN_NODES", "1")
+    monkeypatch.setenv("ARCTE_HIP_PLACEMENT_MIN_MB", "1")
+    monkeypatch.setenv("ARCTE_HIP_PLACEMENT_TRIES", "4")
+    monkeypatch.setenv("ARCTE_HIP_SLOT_SPREAD_MB", "0")
+    _native.trim()
+    try:
+        assert _native.memory_info()["parked_bytes"] == 0
+        with _native.Context(w.indptr, w.indices, w.data, g["out_degree"], g["in_degree"]) as ctx:
+            kept, rates = ctx.placement_info()
+            held = _native.memory_info()
+            slot_bytes = ctx.state_info()["slot_bytes"]
+            assert held["parked_bytes"] <= slot_bytes                                   # one candidate at most
+            assert (held["parked_bytes"] > 0) == (len(rates) > 1)
+            # the slot memory grows (a pushed-state array of 64 entries overflows): the old shape's loser goes back
+            monkeypatch.setenv("ARCTE_HIP_PUSHED", "64")
+        with _native.Context(w.indptr, w.indices, w.data, g["out_degree"], g["in_degree"]) as ctx:
+            before = ctx.state_info()["slot_bytes"]
+            ctx.run_seeds(g["all_seeds"], g["rho"], g["epsilon"])
+            assert ctx.stats()["reruns"] > 0
+            after = ctx.state_info()["slot_bytes"]
+            assert after > before
+            held = _native.memory_info()
+            assert held["parked_bytes"] <= after                                        # of the NEW shape, one at most
+            colptr, rows, nop = ctx.fetch(want_nop=True)
+        assert np.array_equal(colptr, o_colptr) and np.array_equal(nop, o_nop)
+        assert np.array_equal(sorted_rows(colptr, rows), o_rows)
+        monkeypatch.delenv("ARCTE_HIP_PUSHED")
+        monkeypatch.setenv("ARCTE_HIP_PARK_MAX", "0")
+        _native.trim()
+        with _native.Context(w.indptr, w.indices, w.data, g["out_degree"], g["in_degree"]) as ctx:
+            assert _native.memory_info()["parked_bytes"] == 0
+    finally:
+        _native.trim()
+    assert _native.memory_info()["parked_bytes"] == 0 and _native.memory_info()["cached_bytes"] == 0
