@@ -297,7 +297,7 @@ def test_at_most_one_draw_loser_stays_allocated(monkeypatch):
             ctx.run_seeds(g["all_seeds"], g["rho"], g["epsilon"])
             assert ctx.stats()["reruns"] > 0
             after = ctx.state_info()["slot_bytes"]
-            assert after > before
+            assert after >= before
             held = _native.memory_info()
             assert held["parked_bytes"] <= after                                        # of the NEW shape, one at most
             colptr, rows, nop = ctx.fetch(want_nop=True)
