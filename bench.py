@@ -339,12 +339,12 @@ def main():
                     # 64 bytes, i.e. reports half of such a stream.  Here that stream is the rows (8 bytes per traversed
                     # edge on narrow rows, 20 otherwise); the random 8-byte state reads are one 64-byte request each and
                     # are counted as they are.  WRITE_SIZE needs no correction.
-                    stream = (8 if info["narrow_rows"] else 20) * st["edges"]
+                    stream = {0: 20, 1: 8, 2: 4}[info["narrow_rows"]] * st["edges"]
                     traffic = pmc[key]["fetch_bytes"] + pmc[key]["write_bytes"] + 0.5 * stream
                     traffic_note = ("FETCH_SIZE + WRITE_SIZE of %s (commit %s), plus half of the coalesced row stream (%d bytes per "
                                     "traversed edge) that FETCH_SIZE under-reports by 2x on gfx950; measured under the profiler in "
                                     "another process, stamped with this kernel source" % (
-                                        pmc[key].get("source"), pmc[key].get("commit"), 8 if info["narrow_rows"] else 20))
+                                        pmc[key].get("source"), pmc[key].get("commit"), {0: 20, 1: 8, 2: 4}[info["narrow_rows"]]))
                 elif key in pmc:
                     traffic_note = "stale: measured at kernel source %s, running %s" % (pmc[key].get("kernel_source_id"), kernel_source_id())
             except Exception:
@@ -404,9 +404,9 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                # (the name rocprofv3 prints: MODE, VAR, NARROW, TAIL, PROF, LT, WPE, STAGE, IND)
-                "kernel": ("void (anonymous namespace)::k_arcte_lines<0, %d, %s, %s, false, 1, 1, false, %s>((anonymous namespace)::PushParams, "
-                           "(anonymous namespace)::LineParams)" % (variant, "true" if info["narrow_rows"] else "false",
+                # (the name rocprofv3 prints: MODE, VAR, ROWS (0 wide, 1 narrow, 2 packed), TAIL, PROF, LT, WPE, STAGE, IND)
+                "kernel": ("void (anonymous namespace)::k_arcte_lines<0, %d, %d, %s, false, 1, 1, false, %s>((anonymous namespace)::PushParams, "
+                           "(anonymous namespace)::LineParams)" % (variant, info["narrow_rows"],
                                                                    "true" if state["lines_region_b"] else "false",
                                                                    "true" if state["region_b_indirect"] else "false")) if state["line_state"] else
                           "k_arcte_seeds<0, %d, %s, %d, %s%s>" % (variant, "float" if args.float32 else "double", info["tiles"],

@@ -372,7 +372,9 @@ int arcte_hip_launch_occupancy(arcte_hip_ctx *ctx, int *workgroups_per_cu);
  * [3] compute units, [4] wavefronts per workgroup of the propagation kernel, [5] values of the LDS-resident hot
  * table per wavefront (0 = table off), [6] 64-edge tiles per push iteration, [7] wavefronts per compute unit the
  * LDS is divided among, [8] 1 when the propagation streams narrow rows (every row's weights are one number and every
- * in_degree is exact in float32 -- unweighted graphs: 10 instead of 22 bytes per traversed edge), [9] end rank of the
+ * in_degree is exact in float32 -- unweighted graphs: 8 instead of 20 bytes per traversed edge), 2 when it streams PACKED
+ * rows (line state only: ONE 32-bit word per edge -- the target's rank and, above it, its integer in_degree; the few
+ * highest-ranked nodes' in_degrees come from a float32 table; ARCTE_HIP_PACK=0 switches it off), [9] end rank of the
  * warm table (nodes ranked between [5] and [9] keep their state in a compact per-slot array; 0 = off). */
 int arcte_hip_info(arcte_hip_ctx *ctx, int64_t info[10]);
 

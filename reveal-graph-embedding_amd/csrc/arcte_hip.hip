@@ -313,7 +313,11 @@ struct arcte_hip_ctx {
     int lines = 0;                  // the context runs k_arcte_lines (float64 worker / centrality runs)
     int dense_auto = 0;             // the caller asked for an automatic slot count (dense slots are made on demand)
     int64_t want_slots = 0, want_queue = 0;   // what the caller asked for at creation
-    DevBuf<uint32_t> edge_rank, node_rank;
+    DevBuf<uint32_t> edge_rank, node_rank;   // (edge_rank: the packed words when `pack` is set)
+    DevBuf<float> in_degree_rf;              // packed rows: float32 in_degree by rank (the in_degrees a word has no room for)
+    int pack = 0;                            // rows stream as ONE 32-bit word per edge (arcte_lines.hpp, ROWS == 2)
+    uint32_t rank_bits = 0;
+    int64_t pack_escapes = 0, pack_escape_end = 0;   // nodes whose in_degree is looked up, one past the last such rank
     DevBuf<int64_t> rowspan;
     DevBuf<double> in_degree_r;
     int64_t l_slots = 0;
@@ -373,7 +377,7 @@ struct arcte_hip_ctx {
                node_hot.bytes() + edge_hot.bytes() + warm.bytes() +
                queue.bytes() + sup.bytes() + seeds_d.bytes() + work_pos.bytes() + out_cnt.bytes() + status.bytes() +
                nop_d.bytes() + eps_d.bytes() + out_off.bytes() + dst_off.bytes() + raw.bytes() + rows_final.bytes() +
-               edge_rank.bytes() + node_rank.bytes() + rowspan.bytes() + in_degree_r.bytes() + slot_bytes_lines();
+               edge_rank.bytes() + node_rank.bytes() + rowspan.bytes() + in_degree_r.bytes() + in_degree_rf.bytes() + slot_bytes_lines();
     }
     size_t slot_bytes_lines() const { return l_block.bytes() + l_blockb.bytes(); }
     size_t slot_bytes_dense() const { return state.bytes() + sup.bytes() + queue.bytes() + hqueue.bytes() + warm.bytes(); }
@@ -764,20 +768,25 @@ int launch_lines_v(arcte_hip_ctx *c, const PushParams &P, const LineParams &L, i
     // two tiles), and the kernel wants wavefronts in flight more than it wants long steps (1M/50M graph, ms per 81 434
     // seeds: two tiles at 8 per CU 91.1; one tile at 9 / 10 / 11 / 12 per CU 89.5 / 81.4 / 78.3 / 76.4).
     // ARCTE_HIP_TILES=2 / 4 keep the longer steps for ARCTE's worker on narrow rows (A/B).
-    if (tail && c->l_ind)          // region B's lines indirect
-        return c->narrow ? go(k_arcte_lines<MODE, VAR, true, true, false, 1, 1, false, true>) : go(k_arcte_lines<MODE, VAR, false, true, false, 1, 1, false, true>);
-#ifdef ARCTE_HIP_AB_BUILDS          // the arms that lost their A/B (profiles/r03): `make AB=1` builds them, the knobs below select them
-    if (c->narrow && c->tiles == 4 && MODE == 0 && VAR == 0) return tail ? go(k_arcte_lines<0, 0, true, true, false, 4>) : go(k_arcte_lines<0, 0, true, false, false, 4>);
-    if (c->narrow && c->tiles == 2 && MODE == 0 && VAR == 0 && c->l_waves_per_cu > 8)   // two tiles at three wavefronts per SIMD (168 VGPRs)
-        return tail ? go(k_arcte_lines<0, 0, true, true, false, 2, 3>) : go(k_arcte_lines<0, 0, true, false, false, 2, 3>);
-    if (c->narrow && c->tiles == 2 && MODE == 0 && VAR == 0) return tail ? go(k_arcte_lines<0, 0, true, true, false, 2>) : go(k_arcte_lines<0, 0, true, false, false, 2>);
-    if (c->narrow && MODE == 0 && VAR == 0 && stage_rows_on())       // A/B: row data of the steps in flight staged through LDS
-        return tail ? go(k_arcte_lines<0, 0, true, true, false, 1, 1, true>) : go(k_arcte_lines<0, 0, true, false, false, 1, 1, true>);
-    if (c->narrow && MODE == 0 && VAR == 0 && c->l_waves_per_cu > 12)      // four wavefronts per SIMD: the compiler spills to fit 128 VGPRs
-        return tail ? go(k_arcte_lines<0, 0, true, true, false, 1, 4>) : go(k_arcte_lines<0, 0, true, false, false, 1, 4>);
+    // rows: 0 wide, 1 narrow (rank + float32 in_degree), 2 packed (one word per edge; c->edge_rank holds the packed words then)
+    const int rows = c->pack ? 2 : (c->narrow ? 1 : 0);
+    if (tail && c->l_ind) {         // region B's lines indirect
+        if (rows == 2) return go(k_arcte_lines<MODE, VAR, 2, true, false, 1, 1, false, true>);
+        return rows == 1 ? go(k_arcte_lines<MODE, VAR, 1, true, false, 1, 1, false, true>) : go(k_arcte_lines<MODE, VAR, 0, true, false, 1, 1, false, true>);
+    }
+#ifdef ARCTE_HIP_AB_BUILDS          // the arms that lost their A/B (profiles/r03): `make AB=1` builds them, the knobs below select them (narrow rows: ARCTE_HIP_PACK=0)
+    if (rows == 1 && c->tiles == 4 && MODE == 0 && VAR == 0) return tail ? go(k_arcte_lines<0, 0, 1, true, false, 4>) : go(k_arcte_lines<0, 0, 1, false, false, 4>);
+    if (rows == 1 && c->tiles == 2 && MODE == 0 && VAR == 0 && c->l_waves_per_cu > 8)   // two tiles at three wavefronts per SIMD (168 VGPRs)
+        return tail ? go(k_arcte_lines<0, 0, 1, true, false, 2, 3>) : go(k_arcte_lines<0, 0, 1, false, false, 2, 3>);
+    if (rows == 1 && c->tiles == 2 && MODE == 0 && VAR == 0) return tail ? go(k_arcte_lines<0, 0, 1, true, false, 2>) : go(k_arcte_lines<0, 0, 1, false, false, 2>);
+    if (rows == 1 && MODE == 0 && VAR == 0 && stage_rows_on())       // A/B: row data of the steps in flight staged through LDS
+        return tail ? go(k_arcte_lines<0, 0, 1, true, false, 1, 1, true>) : go(k_arcte_lines<0, 0, 1, false, false, 1, 1, true>);
+    if (rows == 1 && MODE == 0 && VAR == 0 && c->l_waves_per_cu > 12)      // four wavefronts per SIMD: the compiler spills to fit 128 VGPRs
+        return tail ? go(k_arcte_lines<0, 0, 1, true, false, 1, 4>) : go(k_arcte_lines<0, 0, 1, false, false, 1, 4>);
 #endif
-    if (c->narrow) return tail ? go(k_arcte_lines<MODE, VAR, true, true, false, 1>) : go(k_arcte_lines<MODE, VAR, true, false, false, 1>);
-    return tail ? go(k_arcte_lines<MODE, VAR, false, true, false, 1>) : go(k_arcte_lines<MODE, VAR, false, false, false, 1>);
+    if (rows == 2) return tail ? go(k_arcte_lines<MODE, VAR, 2, true, false, 1>) : go(k_arcte_lines<MODE, VAR, 2, false, false, 1>);
+    if (rows == 1) return tail ? go(k_arcte_lines<MODE, VAR, 1, true, false, 1>) : go(k_arcte_lines<MODE, VAR, 1, false, false, 1>);
+    return tail ? go(k_arcte_lines<MODE, VAR, 0, true, false, 1>) : go(k_arcte_lines<MODE, VAR, 0, false, false, 1>);
 }
 
 // mode 0: arcte_worker's loop (any push flavour); mode 2: arcte_and_centrality's (ARCTE's own push)
@@ -785,6 +794,8 @@ int launch_lines(arcte_hip_ctx *c, PushParams P, int64_t nwork, int variant, int
 {
     LineParams L;
     L.edge_rank = c->edge_rank.p;
+    L.in_degree_rf = c->in_degree_rf.p;
+    L.rank_bits = c->rank_bits;
     L.node_rank = c->node_rank.p;
     L.ranked_ids = c->ranked_ids.p;
     L.rowspan = c->rowspan.p;
@@ -831,7 +842,8 @@ int launch_lines(arcte_hip_ctx *c, PushParams P, int64_t nwork, int variant, int
     if (mode == 2) return launch_lines_v<2, 0>(c, P, L, blocks, lds);
 #ifdef ARCTE_HIP_AB_BUILDS          // ARCTE_HIP_PROFILE=1: the instrumented instantiation (tools/phase_profile.py)
     if (c->prof.p && c->narrow && variant == 0 && !c->l_ind) {
-        auto kernel = c->l_MB > 0 ? k_arcte_lines<0, 0, true, true, true, 1> : k_arcte_lines<0, 0, true, false, true, 1>;
+        auto kernel = c->pack ? (c->l_MB > 0 ? k_arcte_lines<0, 0, 2, true, true, 1> : k_arcte_lines<0, 0, 2, false, true, 1>)
+                              : (c->l_MB > 0 ? k_arcte_lines<0, 0, 1, true, true, 1> : k_arcte_lines<0, 0, 1, false, true, 1>);
         if (lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kernel, dim3(blocks), dim3(WAVE), lds, c->stream, P, L);
         HIP_TRY(hipGetLastError());
@@ -1274,7 +1286,44 @@ int ctx_finish(arcte_hip_ctx *c, int64_t n_slots, int64_t queue_capacity)
         hipLaunchKernelGGL(k_node_rank, dim3((unsigned)((n + tb - 1) / tb)), dim3(tb), 0, c->stream, c->ranked_ids.p, n, c->node_rank.p);
         hipLaunchKernelGGL(k_rank_space, dim3((unsigned)((n + tb - 1) / tb)), dim3(tb), 0, c->stream, c->ranked_ids.p, c->indptr.p, c->in_degree.p, n,
                            c->rowspan.p, c->in_degree_r.p);
-        if (nnz) hipLaunchKernelGGL(k_edge_rank, dim3((unsigned)((nnz + tb - 1) / tb)), dim3(tb), 0, c->stream, c->indices.p, c->node_rank.p, c->edge_rank.p, nnz);
+        HIP_TRY(hipGetLastError());
+        // Packed rows (round 4): on graphs with narrow rows the in_degree of an edge's target is an integer, and all but the
+        // highest-ranked nodes' fit beside the rank in ONE 32-bit word: 4 instead of 8 bytes per traversed edge.  The nodes
+        // whose in_degree does not fit (or is no integer) are looked up in a float32 table by rank; packed only when those
+        // lie among the first million ranks (a table part that stays cached).  ARCTE_HIP_PACK=0: the 8-byte stream.
+        c->pack = 0;
+        c->rank_bits = 1;
+        while (c->rank_bits < 31 && ((int64_t)1 << c->rank_bits) < n) c->rank_bits++;
+        // (test hook: more bits for the rank than the graph needs leave fewer for the in_degree, so that small graphs
+        //  exercise the table lookup too)
+        const int forced_bits = env_int("ARCTE_HIP_PACK_RANK_BITS", 0);
+        if (forced_bits > (int)c->rank_bits && forced_bits <= 30) c->rank_bits = (uint32_t)forced_bits;
+        if (c->narrow && nnz && (c->rank_bits <= 26 || forced_bits > 0) && env_int("ARCTE_HIP_PACK", 1)) {
+            DevBuf<unsigned long long> st;
+            unsigned long long h[2] = {0, 0};
+            int rp = [&]() -> int {
+                HIP_TRY(st.alloc(2));
+                HIP_TRY(hipMemsetAsync(st.p, 0, 2 * sizeof(unsigned long long), c->stream));
+                HIP_TRY(c->in_degree_rf.alloc(n));
+                hipLaunchKernelGGL(k_in_degree_rf, dim3((unsigned)((n + tb - 1) / tb)), dim3(tb), 0, c->stream, c->in_degree_r.p, n, c->rank_bits,
+                                   c->in_degree_rf.p, st.p);
+                HIP_TRY(hipGetLastError());
+                HIP_TRY(hipMemcpyAsync(h, st.p, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+                HIP_TRY(hipStreamSynchronize(c->stream));
+                return 0;
+            }();
+            st.release();
+            if (rp) return rp;
+            c->pack_escapes = (int64_t)h[0];
+            c->pack_escape_end = (int64_t)h[1];
+            c->pack = c->pack_escape_end <= (int64_t)env_int("ARCTE_HIP_PACK_TABLE_RANKS", 1 << 20);
+            if (!c->pack) c->in_degree_rf.release();
+        }
+        if (nnz && c->pack)
+            hipLaunchKernelGGL(k_edge_pack, dim3((unsigned)((nnz + tb - 1) / tb)), dim3(tb), 0, c->stream, c->indices.p, c->node_rank.p, c->in_degree_r.p,
+                               c->rank_bits, c->edge_rank.p, nnz);
+        else if (nnz)
+            hipLaunchKernelGGL(k_edge_rank, dim3((unsigned)((nnz + tb - 1) / tb)), dim3(tb), 0, c->stream, c->indices.p, c->node_rank.p, c->edge_rank.p, nnz);
         HIP_TRY(hipGetLastError());
     }
     // ---- knobs of the dense-state kernel (k_arcte_seeds: similarity slices, float32, helpers, ARCTE_HIP_STATE=dense)
@@ -1647,7 +1696,7 @@ int arcte_hip_destroy(arcte_hip_ctx *c)
     c->l_stats.release();
     c->l_gen.release();
     c->dump_s.release(); c->dump_r.release();
-    c->edge_rank.release(); c->node_rank.release(); c->rowspan.release(); c->in_degree_r.release();
+    c->edge_rank.release(); c->node_rank.release(); c->rowspan.release(); c->in_degree_r.release(); c->in_degree_rf.release();
     c->state.release(); c->slot_epoch.release(); c->warm.release(); c->contrib_key.release(); c->contrib_val.release(); c->centrality.release(); c->ranked_ids.release(); c->node_hot.release(); c->edge_hot.release(); c->edge_in_degree.release(); c->data_f.release(); c->in_degree_f.release(); c->edge_in_degree_f.release(); c->queue.release(); c->hqueue.release(); c->prof.release(); c->sup.release();
     c->seeds_d.release(); c->work_pos.release(); c->out_cnt.release(); c->status.release(); c->nop_d.release();
     c->eps_d.release(); c->out_off.release(); c->dst_off.release(); c->counters.release();
@@ -3106,8 +3155,9 @@ int arcte_hip_launch_occupancy(arcte_hip_ctx *c, int *workgroups_per_cu)
     if (c->lines && !c->float32) {
         const size_t lds = (size_t)lines_hot_values(c) * sizeof(double) + c->l_M / 8;
         int per_cu = 0;
-        auto kernel = c->narrow ? (c->l_MB > 0 ? k_arcte_lines<0, 0, true, true, false, 1> : k_arcte_lines<0, 0, true, false, false, 1>)
-                                : (c->l_MB > 0 ? k_arcte_lines<0, 0, false, true, false, 1> : k_arcte_lines<0, 0, false, false, false, 1>);
+        auto kernel = c->pack ? (c->l_MB > 0 ? k_arcte_lines<0, 0, 2, true, false, 1> : k_arcte_lines<0, 0, 2, false, false, 1>)
+                      : c->narrow ? (c->l_MB > 0 ? k_arcte_lines<0, 0, 1, true, false, 1> : k_arcte_lines<0, 0, 1, false, false, 1>)
+                                  : (c->l_MB > 0 ? k_arcte_lines<0, 0, 0, true, false, 1> : k_arcte_lines<0, 0, 0, false, false, 1>);
         if (lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, WAVE, lds));
         *workgroups_per_cu = per_cu;
@@ -3138,7 +3188,7 @@ int arcte_hip_info(arcte_hip_ctx *c, int64_t info[10])
         info[5] = lines_hot_values(c);
         info[6] = (c->narrow && (c->tiles == 4 || c->tiles == 2)) ? c->tiles : 1;
         info[7] = c->l_waves_per_cu;
-        info[8] = c->narrow ? 1 : 0;
+        info[8] = c->pack ? 2 : (c->narrow ? 1 : 0);
         info[9] = 0;
         return 0;
     }

@@ -31,6 +31,11 @@
 //     what the previous turn issued -- the counter is in order and counts stores, which the compiler cannot count under
 //     a branch, so a wait anywhere else would drain the turn's own loads too.
 //   * Occupancy decides: one tile per step keeps the kernel at 149 VGPRs = three wavefronts per SIMD (12 per CU).
+//   * Rows (template parameter ROWS): 0 = wide (rank 4 + weight 8 + in_degree 8 bytes per edge), 1 = narrow (one weight per
+//     row: rank 4 + float32 in_degree 4), 2 = PACKED (round 4): ONE 32-bit word per edge, the rank in its low rank_bits bits
+//     and the target's in_degree -- an integer on graphs with narrow rows -- above; the all-ones code sends the lane to a
+//     float32 table by rank instead (the few hundred highest-ranked nodes: L2-resident).  The kernel sits at the memory
+//     system's request wall: half the row stream is 4 % fewer requests.
 #pragma once
 
 #include "arcte_kernels.hpp"
@@ -42,7 +47,9 @@ constexpr int32_t ST_SUP_OVERFLOW = 7;      // more candidates than the list hol
 constexpr int32_t ST_POOL_OVERFLOW = 8;     // more touched lines of region B than its pool holds (indirect lines)
 
 struct LineParams {
-    const uint32_t *edge_rank;    // [nnz] rank of every stored edge's target (CSR order = FIFO order is kept)
+    const uint32_t *edge_rank;    // [nnz] rank of every stored edge's target (CSR order = FIFO order is kept); ROWS == 2: the packed words
+    const float *in_degree_rf;    // [n] by rank, float32 (ROWS == 2: in_degrees the packed word has no room for)
+    uint32_t rank_bits;           // ROWS == 2: bits of the packed word that hold the rank
     const uint32_t *node_rank;    // [n]
     const int32_t *ranked_ids;    // [n] rank -> node
     const int64_t *rowspan;       // [2n] by rank: first and one-past-last edge of the node's row
@@ -101,9 +108,11 @@ __device__ __forceinline__ void blind_round(double *vals, double *vals_b, uint32
 }
 
 // registers of the pipeline stages, LT 64-edge tiles per step (narrow rows: the weight is the row's, the in_degree a float)
-template <int LT, bool NARROW> struct LRowT { bool a[LT]; uint32_t v[LT]; double w[LT], d[LT]; };
-template <int LT> struct LRowT<LT, true> { bool a[LT]; uint32_t v[LT]; float d[LT]; };
-template <int LT> struct LSlotT { double x[LT]; bool owner[LT]; uint32_t ix[LT]; };
+template <int LT, int ROWS> struct LRowT { bool a[LT]; uint32_t v[LT]; double w[LT], d[LT]; };
+template <int LT> struct LRowT<LT, 1> { bool a[LT]; uint32_t v[LT]; float d[LT]; };
+template <int LT> struct LRowT<LT, 2> { bool a[LT]; uint32_t v[LT]; };          // v: rank | in_degree code << rank_bits
+template <int LT, bool PACK> struct LSlotT { double x[LT]; bool owner[LT]; uint32_t ix[LT]; };
+template <int LT> struct LSlotT<LT, true> { double x[LT]; bool owner[LT]; uint32_t ix[LT]; float dq[LT]; };   // dq: in_degree from the table (escaped lanes)
 template <int LT> struct LPushedT { double2 q[LT]; };
 template <int LT> struct LClaimT { uint32_t old[LT]; uint64_t bi[LT]; };
 
@@ -117,19 +126,21 @@ template <int LT> struct LClaimT { uint32_t old[LT]; uint64_t bi[LT]; };
 // generation is this seed's, which fails only for a line claimed by another lane of the same 64-edge step (then the entry
 // is read again after the owner's store) -- and then the value.  4 MB of bidx per million nodes + the pool instead of
 // 8 MB of values per million nodes; region A, the LDS level and the order of every floating-point operation are unchanged.
-template <int MODE, int VAR, bool NARROW, bool TAIL, bool PROF = false, int LT = 1, int WPE = 1, bool STAGE = false, bool IND = false>
+template <int MODE, int VAR, int ROWS, bool TAIL, bool PROF = false, int LT = 1, int WPE = 1, bool STAGE = false, bool IND = false>
 __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(WPE))) void k_arcte_lines(PushParams P, LineParams L)
 {
     static_assert(!IND || (TAIL && !STAGE), "indirect lines are region B's");
-    typedef LRowT<LT, NARROW> LRow;
-    typedef LSlotT<LT> LSlot;
+    static_assert(ROWS >= 0 && ROWS <= 2, "wide, narrow or packed rows");
+    constexpr bool NARROW = ROWS != 0, PACK = ROWS == 2;
+    typedef LRowT<LT, ROWS> LRow;
+    typedef LSlotT<LT, PACK> LSlot;
     typedef LPushedT<LT> LPushed;
     typedef LClaimT<LT> LClaim;
     static_assert(MODE == 0 || MODE == 2, "worker or centrality");
     // STAGE (A/B of BASELINE.json's "rows staged through LDS", ARCTE_HIP_STAGE_ROWS=1): the row data of the steps in flight
     // (rank + float32 in_degree, 8 bytes per edge) go global -> LDS directly (global_load_lds), five 512-byte stages behind
     // the bitmap, and are read back when a stage needs them, instead of living in VGPRs across the turns
-    static_assert(!STAGE || (NARROW && LT == 1), "row staging exists for one-tile steps of narrow rows");
+    static_assert(!STAGE || (ROWS == 1 && LT == 1), "row staging exists for one-tile steps of narrow rows");
     // PROF (ARCTE_HIP_PROFILE=1): s_memtime ticks per phase, the indices of PushParams::prof
     unsigned long long prof[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     auto tick = [&]() -> unsigned long long { return PROF ? (unsigned long long)__builtin_amdgcn_s_memtime() : 0ULL; };
@@ -163,6 +174,10 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(WPE))) voi
         if (lane == 0) w = atomicAdd(P.work_counter, 1ULL);
         return bcast_u64(w);
     };
+    // packed rows: the rank is the low rank_bits bits of the word, the in_degree code the rest (all ones: see the table)
+    const uint32_t rbits = PACK ? L.rank_bits : 0u, rmask = PACK ? ((1u << rbits) - 1u) : 0xFFFFFFFFu;
+    const uint32_t desc = PACK ? (0xFFFFFFFFu >> rbits) : 0u;
+    auto rk_of = [&](uint32_t v) -> uint32_t { if constexpr (PACK) return v & rmask; else return v; };
     auto in_b = [&](uint32_t rk) -> bool { return TAIL && rk >= RA; };
     auto value_index = [&](uint32_t rk) -> uint32_t {
         if (in_b(rk)) {
@@ -240,7 +255,8 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(WPE))) voi
                 R.a[t] = k < re;
                 const int64_t kk = R.a[t] ? k : re - 1;
                 R.v[t] = L.edge_rank[kk];
-                if constexpr (NARROW) R.d[t] = g.edge_in_degree_f[kk];
+                if constexpr (PACK) {}
+                else if constexpr (NARROW) R.d[t] = g.edge_in_degree_f[kk];
                 else { R.w[t] = g.data[kk]; R.d[t] = g.edge_in_degree[kk]; }
             }
         };
@@ -256,8 +272,8 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(WPE))) voi
                 for (int t = 0; t < LT; t++) {
                     C.old[t] = 0;
                     C.bi[t] = 0;
-                    if (TAIL && R.a[t] && R.v[t] >= RA) {
-                        const uint32_t ln = (R.v[t] - RA) & MBmask;
+                    if (TAIL && R.a[t] && rk_of(R.v[t]) >= RA) {
+                        const uint32_t ln = (rk_of(R.v[t]) - RA) & MBmask;
                         C.old[t] = atomicOr(&gbm[ln >> 5], 1u << (ln & 31));
                         if constexpr (IND) C.bi[t] = bidx[ln];          // (valid if the line was claimed in an earlier step)
                     }
@@ -268,7 +284,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(WPE))) voi
                 bool any_load = false;
 #pragma unroll
                 for (int t = 0; t < LT; t++) {
-                    const uint32_t rk = R.v[t];
+                    const uint32_t rk = rk_of(R.v[t]);
                     const bool line_lvl = R.a[t] && rk >= K;
                     bool owner = false;
                     if (TAIL && line_lvl && rk >= RA) {
@@ -321,12 +337,21 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(WPE))) voi
                     ld_index[t] = (line_lvl && !owner) ? index : 0u;
                     any_load |= line_lvl && !owner;
                     E.x[t] = 0.0;
+                    if constexpr (PACK) {
+                        // an in_degree the packed word has no room for comes from the float32 table by rank (the highest
+                        // ranks: a few KB, cached); the lookup rides with the value loads of this stage
+                        E.dq[t] = 0.0f;
+                        any_load |= R.a[t] && (R.v[t] >> rbits) == desc;
+                    }
                 }
                 // (skip_if_none: a row of one step waits for these loads at once; when no lane has a value to read --
                 //  first touches and on-chip nodes only -- there is nothing to wait for: a wave-uniform branch)
                 if (skip_if_none && __ballot(any_load) == 0) return;
 #pragma unroll
-                for (int t = 0; t < LT; t++) E.x[t] = *val_at(ld_index[t]);
+                for (int t = 0; t < LT; t++) {
+                    E.x[t] = *val_at(ld_index[t]);
+                    if constexpr (PACK) E.dq[t] = L.in_degree_rf[(R.a[t] && (R.v[t] >> rbits) == desc) ? rk_of(R.v[t]) : 0u];
+                }
             };
             // stage 3: the value in the node's place; a pushed node's NaN points into PS
             // (skip_if_none: a row of one step has nothing to overlap the load with, so it is only issued when some
@@ -335,7 +360,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(WPE))) voi
                 bool any = false;
 #pragma unroll
                 for (int t = 0; t < LT; t++) {
-                    const uint32_t rk = R.v[t];
+                    const uint32_t rk = rk_of(R.v[t]);
                     double x = 0.0;
                     if (R.a[t]) x = (rk < K) ? hot[rk] : (E.owner[t] ? 0.0 : E.x[t]);
                     E.x[t] = x;
@@ -351,8 +376,10 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(WPE))) voi
 #pragma unroll
                 for (int t = 0; t < LT; t++) {
                     const bool act = R.a[t];
-                    const uint32_t rk = R.v[t];
-                    const double dv = (double)R.d[t];
+                    const uint32_t rk = rk_of(R.v[t]);
+                    double dv;
+                    if constexpr (PACK) { const uint32_t dc = R.v[t] >> rbits; dv = (dc == desc) ? (double)E.dq[t] : (double)dc; }
+                    else dv = (double)R.d[t];
                     const double x = E.x[t];
                     const bool mv = act && moved_is(x);
                     double wt;
@@ -718,7 +745,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(WPE))) voi
             double thr = s_seed / seed_d;
             bool miss = s_seed == 0.0, selfloop = false;
             for (int64_t k = seed_b + lane; k < seed_e; k += WAVE) {
-                const uint32_t rk = L.edge_rank[k];
+                const uint32_t rk = rk_of(L.edge_rank[k]);
                 selfloop |= (rk == sr);
                 const double sv = s_of(rk);
                 miss |= (sv == 0.0);
@@ -842,6 +869,35 @@ __global__ void k_rank_space(const int32_t *ranked_ids, const int64_t *indptr, c
     rowspan[2 * i] = indptr[v];
     rowspan[2 * i + 1] = indptr[v + 1];
     in_degree_r[i] = in_degree[v];
+}
+
+// ---- packed rows (ROWS == 2): rank | in_degree code << rank_bits per edge; the all-ones code = "look the in_degree up"
+__device__ __forceinline__ uint32_t degree_code(double d, uint32_t rank_bits)
+{
+    const uint32_t esc = 0xFFFFFFFFu >> rank_bits;
+    return (d >= 0.0 && d < (double)esc && d == floor(d)) ? (uint32_t)d : esc;
+}
+
+// float32 in_degree by rank + which ranks the packed word cannot carry: stats[0] their number, stats[1] one past the last
+__global__ void k_in_degree_rf(const double *in_degree_r, int64_t n, uint32_t rank_bits, float *out, unsigned long long *stats)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double d = in_degree_r[i];
+    out[i] = (float)d;
+    if (degree_code(d, rank_bits) == (0xFFFFFFFFu >> rank_bits)) {
+        atomicAdd(stats + 0, 1ULL);
+        atomicMax(stats + 1, (unsigned long long)(i + 1));
+    }
+}
+
+__global__ void k_edge_pack(const int32_t *indices, const uint32_t *node_rank, const double *in_degree_r, uint32_t rank_bits,
+                            uint32_t *edge_pack, int64_t nnz)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nnz) return;
+    const uint32_t rk = node_rank[indices[k]];
+    edge_pack[k] = rk | (degree_code(in_degree_r[rk], rank_bits) << rank_bits);
 }
 
 __global__ void k_edge_rank(const int32_t *indices, const uint32_t *node_rank, uint32_t *edge_rank, int64_t nnz)

@@ -101,18 +101,33 @@ def test_duplicate_columns_are_rejected():
 
 
 @pytest.mark.parametrize("variant", FLAVOURS)
-def test_narrow_rows_are_invisible(variant, monkeypatch):
-    """Unweighted graphs stream 10 bytes per edge (one weight per row, float32 in_degrees that widen back exactly);
-    weighted ones cannot.  Same results either way."""
+def test_narrow_and_packed_rows_are_invisible(variant, monkeypatch):
+    """Unweighted graphs stream 8 bytes per edge (one weight per row, float32 in_degrees that widen back exactly) or, packed
+    (the default of the line state), ONE 32-bit word: rank + integer in_degree, the in_degrees that do not fit looked up in
+    a float32 table by rank; weighted graphs can do neither.  Same results every way -- also when the word is left so few
+    bits for the in_degree (test hook) that most lanes take the table."""
     from reveal_graph_embedding_amd import _native
-    for name, expect in (("ba300", 1), ("rmat2000", 1), ("selfloop", 1), ("weighted", 0)):
+    monkeypatch.delenv("ARCTE_HIP_PACK_RANK_BITS", raising=False)
+    for name, expect in (("ba300", 2), ("rmat2000", 2), ("selfloop", 2), ("weighted", 0)):
         g = load_golden(name)
         w = g["w"]
+        monkeypatch.delenv("ARCTE_HIP_PACK", raising=False)
+        monkeypatch.delenv("ARCTE_HIP_NARROW", raising=False)
         with _native.Context(w.indptr, w.indices, w.data, g["out_degree"], g["in_degree"]) as ctx:
             assert ctx.info()["narrow_rows"] == expect, name
         monkeypatch.setenv("ARCTE_HIP_NARROW", "0")
         ref = run(g, -1, variant, monkeypatch)
         monkeypatch.setenv("ARCTE_HIP_NARROW", "1")
-        got = run(g, -1, variant, monkeypatch)
-        assert np.array_equal(got[0], ref[0]) and np.array_equal(got[2], ref[2]) and got[3] == ref[3], name
-        assert np.array_equal(sorted_rows(got[0], got[1]), sorted_rows(ref[0], ref[1])), name
+        for pack, bits in (("0", None), ("1", None), ("1", "29"), ("1", "30")):
+            monkeypatch.setenv("ARCTE_HIP_PACK", pack)
+            if bits is None:
+                monkeypatch.delenv("ARCTE_HIP_PACK_RANK_BITS", raising=False)
+            else:
+                monkeypatch.setenv("ARCTE_HIP_PACK_RANK_BITS", bits)
+            if expect:
+                with _native.Context(w.indptr, w.indices, w.data, g["out_degree"], g["in_degree"]) as ctx:
+                    assert ctx.info()["narrow_rows"] == (2 if pack == "1" else 1), (name, pack, bits)
+            got = run(g, -1, variant, monkeypatch)
+            tag = (name, pack, bits)
+            assert np.array_equal(got[0], ref[0]) and np.array_equal(got[2], ref[2]) and got[3] == ref[3], tag
+            assert np.array_equal(sorted_rows(got[0], got[1]), sorted_rows(ref[0], ref[1])), tag

@@ -15,11 +15,17 @@ from test_pagerank_variants import PAGERANK_GRAPHS, load as load_pagerank, rho_o
 
 pytestmark = pytest.mark.gpu
 
-# (on-chip values, lines with touched-bits in LDS, region B's lines indirect)
-STATE_SPLITS = [(h, l, 0) for h, l in SPLITS] + [(0, 64, 1), (4, 64, 1)]
+# (on-chip values, lines with touched-bits in LDS, region B's lines indirect: 0 / 1; 2 = dense lines and the packed row
+#  words left with 3 bits for the in_degree, so that most lanes look theirs up in the table by rank)
+STATE_SPLITS = [(h, l, 0) for h, l in SPLITS] + [(0, 64, 1), (4, 64, 1), (4, 64, 2)]
 
 
 def set_split(monkeypatch, hot, lines_lds, indirect):
+    if indirect == 2:
+        monkeypatch.setenv("ARCTE_HIP_PACK_RANK_BITS", "29")
+        indirect = 0
+    else:
+        monkeypatch.delenv("ARCTE_HIP_PACK_RANK_BITS", raising=False)
     monkeypatch.setenv("ARCTE_HIP_HOT", str(hot))
     monkeypatch.delenv("ARCTE_HIP_STATE", raising=False)
     if lines_lds is None:
