@@ -147,6 +147,16 @@ int arcte_hip_run_seeds_variant(arcte_hip_ctx *ctx, const int64_t *seeds, int64_
                                 int variant, double laziness_factor);
 
 /*
+ * The same for ONE MORE part of a seed list: the completed run's result stays on the context and this run's columns join it
+ * (the result then lists the new seeds first, the earlier ones behind them; the CSR assembly orders columns by seed id).  The
+ * reference's counterpart is the sum over the chunks of a worker (arcte.py:384-386) -- every seed owns its column, so the sum is
+ * a concatenation.  Counters and timings of arcte_hip_run_stats / _counters / _timing add up over the parts.
+ * ARCTE_HIP_ESTATE without a completed (non-centrality) run to append to.
+ */
+int arcte_hip_run_seeds_append(arcte_hip_ctx *ctx, const int64_t *seeds, int64_t nseeds, double rho, double epsilon,
+                               int use_effective_epsilon, int variant, double laziness_factor);
+
+/*
  * The loop of arcte_and_centrality (embedding/arcte/cython_opt/arcte.pyx:165-217), the reference's older
  * single-process driver, for the nodes in [node_begin, node_end): every node WITH out-edges is a seed, in index order;
  * the propagation runs with the RAW epsilon; s/in_degree of every support node is added to a centrality vector in

@@ -37,6 +37,8 @@ SIGNATURES = {
     "arcte_hip_run_seeds": (C.c_int, [C.c_void_p, _i64p, C.c_int64, C.c_double, C.c_double, C.c_int]),
     "arcte_hip_run_seeds_variant": (C.c_int, [C.c_void_p, _i64p, C.c_int64, C.c_double, C.c_double, C.c_int, C.c_int,
                                               C.c_double]),
+    "arcte_hip_run_seeds_append": (C.c_int, [C.c_void_p, _i64p, C.c_int64, C.c_double, C.c_double, C.c_int, C.c_int,
+                                             C.c_double]),
     "arcte_hip_run_centrality": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_double, C.c_double]),
     "arcte_hip_fetch_centrality": (C.c_int, [C.c_void_p, _f64p]),
     "arcte_hip_result_sizes": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
@@ -337,11 +339,12 @@ class Context:
         _check(lib().arcte_hip_epsilon_effective(self._h, seeds, seeds.size, float(epsilon), out))
         return out
 
-    def run_seeds(self, seeds, rho, epsilon, use_effective_epsilon=True, variant=ARCTE, laziness_factor=0.5):
+    def run_seeds(self, seeds, rho, epsilon, use_effective_epsilon=True, variant=ARCTE, laziness_factor=0.5, append=False):
+        """append=True: one more part of a seed list; the completed run's result stays and this run's columns join it."""
         seeds = np.ascontiguousarray(seeds, dtype=np.int64)
-        _check(lib().arcte_hip_run_seeds_variant(self._h, seeds, seeds.size, float(rho), float(epsilon),
-                                                 1 if use_effective_epsilon else 0, int(variant),
-                                                 float(laziness_factor)))
+        fn = lib().arcte_hip_run_seeds_append if append else lib().arcte_hip_run_seeds_variant
+        _check(fn(self._h, seeds, seeds.size, float(rho), float(epsilon), 1 if use_effective_epsilon else 0, int(variant),
+                  float(laziness_factor)))
 
     def run_centrality(self, rho, epsilon, node_begin=0, node_end=None):
         """The loop of arcte_and_centrality (arcte.pyx:165-217) for the nodes in [node_begin, node_end)."""
@@ -380,12 +383,18 @@ class Context:
         _check(lib().arcte_hip_result_csr_size(self._h, 1 if with_base_block else 0, C.byref(nnz)))
         return int(nnz.value)
 
-    def fetch_csr(self, with_base_block=False):
+    def fetch_csr(self, with_base_block=False, out_indices=None):
         """The last run as CSR (indptr int64[n+1], indices int32), assembled on the device.  With the base block
-        the columns are those of arcte()'s n x 2n matrix.  Seeds must have been unique."""
+        the columns are those of arcte()'s n x 2n matrix.  Seeds must have been unique.  out_indices: a C-contiguous int32
+        array of at least result_csr_size() entries to receive the column ids (e.g. one whose pages are faulted in already)."""
         nnz = self.result_csr_size(with_base_block)
         indptr = np.zeros(self.n + 1, dtype=np.int64)
-        indices = np.empty(max(nnz, 1), dtype=np.int32)
+        if out_indices is not None:
+            if out_indices.dtype != np.int32 or not out_indices.flags.c_contiguous or out_indices.size < max(nnz, 1):
+                raise ValueError("out_indices must be a C-contiguous int32 array of at least %d entries" % max(nnz, 1))
+            indices = out_indices
+        else:
+            indices = np.empty(max(nnz, 1), dtype=np.int32)
         got = C.c_int64(0)
         _check(lib().arcte_hip_fetch_result_csr(self._h, 1 if with_base_block else 0, indptr, indices.ctypes.data,
                                                 C.byref(got)))

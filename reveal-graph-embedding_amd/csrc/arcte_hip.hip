@@ -349,6 +349,7 @@ struct arcte_hip_ctx {
     DevBuf<int32_t> sort_iota, eps_big_pos;
     DevBuf<char> sort_temp;
     int64_t raw_for_seeds = 0;
+    int64_t rows_reserve_extra = 0;   // rows a running call leaves room for behind its own (arcte_hip_run_seeds_append)
     int64_t final_rows = 0;
     std::vector<int64_t> colptr;
     int64_t stats[6] = {0, 0, 0, 0, 0, 0};
@@ -592,7 +593,7 @@ int draw_slot_memory(arcte_hip_ctx *c, size_t slots, size_t block)
     free_parked_on(c->device, bytes);          // losers of a draw of another shape: of no use to this one
     // A draw may cost this much allocation time before it settles for what it holds (on some boxes a hipMalloc of tens of
     // GB takes a second or more, profiles/r03/first_call_1m.txt: there the third candidate is not worth its price)
-    const double alloc_budget_s = std::max(0, env_int("ARCTE_HIP_DRAW_ALLOC_MS", 1200)) * 1e-3;
+    const double alloc_budget_s = std::max(0, env_int("ARCTE_HIP_DRAW_ALLOC_MS", 400)) * 1e-3;
     double alloc_spent_s = 0.0;
     std::vector<SlotMem> cand((size_t)tries);
     DevBuf<unsigned long long> sink;
@@ -2053,7 +2054,7 @@ static int run_seeds_impl(arcte_hip_ctx *c, const int64_t *seeds, int64_t nseeds
             if ((size_t)(final_used + add) > c->rows_final.count) {
                 DevBuf<int32_t> bigger;
                 ScopedRelease<int32_t> bigger_guard(bigger);
-                size_t want = std::max<size_t>((size_t)(final_used + add), c->rows_final.count * 2);
+                size_t want = std::max<size_t>((size_t)(final_used + add + c->rows_reserve_extra), c->rows_final.count * 2);
                 HIP_TRY(alloc_cached(bigger, want, c->device));
                 if (final_used)
                     HIP_TRY(hipMemcpyAsync(bigger.p, c->rows_final.p, final_used * sizeof(int32_t), hipMemcpyDeviceToDevice, c->stream));
@@ -2503,6 +2504,46 @@ int arcte_hip_append_result(arcte_hip_ctx *c, const int64_t *seeds, const int64_
     for (int64_t k = 0; k < nseeds; k++) c->colptr[(size_t)(ns0 + k) + 1] = c->colptr[(size_t)(ns0 + k)] + counts[k];
     c->run_nseeds = ns0 + nseeds;
     c->final_rows = rows0 + nrows;
+    return 0;
+}
+
+// A second (third, ...) part of a seed list on one context: the completed run's result stays and this run's columns join it, as
+// if arcte_hip_append_result had been handed them -- what lets a caller size and fault in its host arrays from the first part
+// while the rest of the seeds runs (embedding/arcte/arcte.py).  The reference's counterpart is the sum of the chunk matrices
+// (arcte.py:384-386, 670-673); every seed owns its column, so the sum is a concatenation.
+int arcte_hip_run_seeds_append(arcte_hip_ctx *c, const int64_t *seeds, int64_t nseeds, double rho, double epsilon,
+                               int use_effective_epsilon, int variant, double laziness_factor)
+{
+    if (!c) return fail(ARCTE_HIP_EINVAL, "bad argument");
+    if (c->run_nseeds < 0) return fail(ARCTE_HIP_ESTATE, "no completed run on this context to append to");
+    if (c->centrality_run) return fail(ARCTE_HIP_ESTATE, "the columns of a centrality run are numbered by a running counter: parts cannot be appended");
+    HIP_TRY(hipSetDevice(c->device));
+    // the completed part steps aside: seeds and sizes on the host, rows where they are
+    const int64_t ns0 = c->run_nseeds, rows0 = c->final_rows;
+    std::vector<int32_t> s32((size_t)std::max<int64_t>(ns0, 1));
+    if (ns0) HIP_TRY(hipMemcpy(s32.data(), c->seeds_d.p, ns0 * sizeof(int32_t), hipMemcpyDeviceToHost));
+    std::vector<int64_t> seeds0((size_t)ns0), counts0((size_t)ns0);
+    for (int64_t k = 0; k < ns0; k++) {
+        seeds0[(size_t)k] = s32[(size_t)k];
+        counts0[(size_t)k] = c->colptr[(size_t)k + 1] - c->colptr[(size_t)k];
+    }
+    int64_t stats0[6], cand0 = c->candidates, split0 = c->split_rows, lines0[4];
+    double ms0[4];
+    for (int i = 0; i < 6; i++) stats0[i] = c->stats[i];
+    for (int i = 0; i < 4; i++) { lines0[i] = c->line_stats[i]; ms0[i] = c->ms[i]; }
+    DevBuf<int32_t> rows_prev = c->rows_final;
+    ScopedRelease<int32_t> rows_prev_guard(rows_prev);
+    c->rows_final = DevBuf<int32_t>();
+    c->rows_reserve_extra = rows0;
+    int rc = run_seeds_impl(c, seeds, nseeds, rho, epsilon, use_effective_epsilon, variant, laziness_factor);
+    c->rows_reserve_extra = 0;
+    if (rc) return rc;
+    rc = arcte_hip_append_result(c, seeds0.data(), counts0.data(), ns0, rows_prev.p, rows0);
+    if (rc) { c->run_nseeds = -1; return rc; }
+    for (int i = 0; i < 6; i++) c->stats[i] += stats0[i];
+    for (int i = 0; i < 4; i++) { c->line_stats[i] += lines0[i]; c->ms[i] += ms0[i]; }
+    c->candidates += cand0;
+    c->split_rows += split0;
     return 0;
 }
 

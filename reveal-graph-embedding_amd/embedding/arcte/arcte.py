@@ -91,6 +91,39 @@ class _OnesInBackground:
         return self._out
 
 
+class _HostArraysInBackground:
+    """The two large host arrays of the result matrix -- the values (float64 ones, arcte.py:381) and the column ids the device
+    will copy out -- allocated for `capacity` entries and written / faulted in by background threads WHILE the GPU runs the
+    rest of the seeds: a device-to-host copy into pages that have never been touched runs at a fifth of the PCIe rate
+    (tools/d2h_rate.hip: 11.6 against 53.5 GB/s), and np.ones(nnz) alone took 0.48 s of arcte()'s 1.05 s on the 1M-node graph."""
+
+    def __init__(self, capacity):
+        self.capacity = int(capacity)
+        self.ones = np.empty(self.capacity, dtype=np.float64)
+        self.indices = np.empty(max(self.capacity, 1), dtype=np.int32)
+        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        threads = max(1, min(24, cores - 1, self.capacity >> 22))
+        step = -(-self.capacity // threads) if self.capacity else 0
+        self._threads = []
+        for k in range(threads if self.capacity else 0):
+            self._threads.append(threading.Thread(target=self._fill, args=(k * step, min(self.capacity, (k + 1) * step))))
+        for t in self._threads:
+            t.start()
+
+    def _fill(self, lo, hi):
+        self.ones[lo:hi].fill(1.0)
+        self.indices[lo:hi].fill(0)
+
+    def wait(self):
+        for t in self._threads:
+            t.join()
+
+
+# a run of at least this many seeds is split into a sizing part and the rest (below)
+_SPLIT_MIN_SEEDS = 65536
+_SIZING_STRIDE = 8
+
+
 def _features_of_run(ctx, variant, iterate_nodes, rho, epsilon, with_base_block, pattern):
     """Run `iterate_nodes` on the context and return the reference's matrix: n x n local communities
     (arcte.py:379-388) or, with the base block, arcte()'s n x 2n [I + pattern | local] (arcte.py:676-683).
@@ -100,9 +133,43 @@ def _features_of_run(ctx, variant, iterate_nodes, rho, epsilon, with_base_block,
     laziness_factor = 0.5
     if variant == _native.LAZY_PAGERANK:
         rho = (rho*(0.5))/(1-(0.5*rho))          # lazy_rho, reference arcte.py:109
-    ctx.run_seeds(iterate_nodes, rho, epsilon, use_effective_epsilon=True, variant=variant,
-                  laziness_factor=laziness_factor)
-    if with_base_block or np.unique(iterate_nodes).size == iterate_nodes.size:
+    unique = with_base_block or np.unique(iterate_nodes).size == iterate_nodes.size
+    result_order = iterate_nodes                    # the seeds in the order the context lists their columns
+    if unique and iterate_nodes.size >= _SPLIT_MIN_SEEDS and not os.environ.get("ARCTE_HIP_NO_SPLIT_RUN"):
+        # Large runs go in TWO launches: every eighth seed first (the list's own mix: its emitted rows times eight size the
+        # result within a per cent), then the others -- and while those run, background threads allocate, fill and fault in the
+        # host arrays the result will land in.  The device assembly + copy-out that follows finds touched pages.
+        sizing = iterate_nodes[::_SIZING_STRIDE]
+        keep = np.ones(iterate_nodes.size, dtype=bool)
+        keep[::_SIZING_STRIDE] = False
+        result_order = np.concatenate([iterate_nodes[keep], sizing])          # (an appended run lists its own seeds first)
+        ctx.run_seeds(sizing, rho, epsilon, use_effective_epsilon=True, variant=variant, laziness_factor=laziness_factor)
+        _, rows_first = ctx.result_sizes()
+        base_entries = ctx.result_csr_size(with_base_block) - rows_first
+        estimate = base_entries + int(rows_first * (iterate_nodes.size / max(sizing.size, 1)) * 1.04) + (1 << 20)
+        host = _HostArraysInBackground(estimate)
+        try:
+            ctx.run_seeds(iterate_nodes[keep], rho, epsilon, use_effective_epsilon=True, variant=variant,
+                          laziness_factor=laziness_factor, append=True)
+        finally:
+            host.wait()
+        nnz = ctx.result_csr_size(with_base_block)
+        if nnz <= host.capacity:
+            try:
+                indptr, indices = ctx.fetch_csr(with_base_block, out_indices=host.indices)
+            except _native.ArcteHipError as e:
+                if e.code != -3:                  # ARCTE_HIP_ECAPACITY: too many entries for the device assembly
+                    raise
+            else:
+                width = 2 * number_of_nodes if with_base_block else number_of_nodes
+                index_dtype = np.int32 if max(width, indices.size) < 2 ** 31 else np.int64
+                return sparse.csr_matrix((host.ones[:indices.size], indices.astype(index_dtype, copy=False),
+                                          indptr.astype(index_dtype)), shape=(number_of_nodes, width))
+        del host
+    else:
+        ctx.run_seeds(iterate_nodes, rho, epsilon, use_effective_epsilon=True, variant=variant,
+                      laziness_factor=laziness_factor)
+    if unique:
         # the device sorts the (row, seed) pairs into the CSR the reference builds via COO (arcte.py:379-388); the
         # host meanwhile writes the matrix's values (all ones, arcte.py:381) -- 7 GB on the 1M-node graph
         ones = None
@@ -120,7 +187,7 @@ def _features_of_run(ctx, variant, iterate_nodes, rho, epsilon, with_base_block,
             return sparse.csr_matrix((ones.result()[:indices.size], indices.astype(index_dtype, copy=False),
                                       indptr.astype(index_dtype)), shape=(number_of_nodes, width))
     colptr, rows = ctx.fetch()
-    local = _seed_matrix(number_of_nodes, iterate_nodes, colptr, rows)
+    local = _seed_matrix(number_of_nodes, result_order, colptr, rows)
     if not with_base_block:
         return local
     base = sparse.csr_matrix(sparse.eye(number_of_nodes, number_of_nodes, dtype=np.float64)) + pattern()

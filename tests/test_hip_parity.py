@@ -451,3 +451,52 @@ def test_fastest_context_returns_a_working_context():
         ref.run_seeds(seeds, 0.1, 1e-5)
         want = ref.fetch(want_nop=True)
     assert all(np.array_equal(a, b) for a, b in zip(got, want))
+
+
+def test_appended_runs_equal_one_run(golden):
+    """arcte_hip_run_seeds_append: a seed list run in parts on one context (the reference sums the chunk matrices of a worker,
+    arcte.py:384-386) gives every seed the column, push count and counters of a single run."""
+    seeds = golden["all_seeds"]
+    if seeds.size < 6:
+        pytest.skip("too few seeds to split")
+    with ctx_of(golden) as ctx:
+        ctx.run_seeds(seeds, golden["rho"], golden["epsilon"])
+        colptr, rows, nop = ctx.fetch(want_nop=False) + (None,)
+        st = ctx.stats()
+        ref = {int(s): np.sort(rows[colptr[k]:colptr[k + 1]]) for k, s in enumerate(seeds)}
+        ref_csr = ctx.fetch_csr(True)
+        parts = [seeds[0::3], seeds[1::3], seeds[2::3]]
+        ctx.run_seeds(parts[0], golden["rho"], golden["epsilon"])
+        ctx.run_seeds(parts[1], golden["rho"], golden["epsilon"], append=True)
+        ctx.run_seeds(parts[2], golden["rho"], golden["epsilon"], append=True)
+        colptr2, rows2 = ctx.fetch()
+        order = np.concatenate([parts[2], parts[1], parts[0]])          # an appended run lists its own seeds first
+        assert colptr2.size == seeds.size + 1
+        for k, s in enumerate(order):
+            assert np.array_equal(np.sort(rows2[colptr2[k]:colptr2[k + 1]]), ref[int(s)]), int(s)
+        st2 = ctx.stats()
+        for key in ("pushes", "edges", "enqueues", "support"):
+            assert st2[key] == st[key], key
+        got_csr = ctx.fetch_csr(True)
+        assert np.array_equal(got_csr[0], ref_csr[0]) and np.array_equal(got_csr[1], ref_csr[1])
+    with ctx_of(golden) as ctx:
+        with pytest.raises(_native.ArcteHipError) as e:
+            ctx.run_seeds(seeds, golden["rho"], golden["epsilon"], append=True)         # nothing to append to
+        assert e.value.code == -4
+
+
+def test_arcte_in_two_launches_with_background_host_arrays(golden, monkeypatch):
+    """Large runs of arcte() / arcte_worker() go in two launches (a sizing part, then the rest while the host arrays are
+    faulted in): forced onto the fixtures, the matrices must be the reference's."""
+    from reveal_graph_embedding_amd.embedding.arcte import arcte as A
+    monkeypatch.setattr(A, "_SPLIT_MIN_SEEDS", 4)
+    got = A.arcte(golden["adjacency"], golden["rho"], golden["epsilon"], 1)
+    assert_same_sparse(got, golden["feat1"])
+    w = golden["w"]
+    got = A.arcte_worker(golden["seeds"], w.indices, w.indptr, w.data, golden["out_degree"], golden["in_degree"],
+                         golden["rho"], golden["epsilon"])
+    assert_same_sparse(got, golden["worker"])
+    # the host-assembly fallback (more entries than the device assembly takes) with the parts' seed order
+    monkeypatch.setenv("ARCTE_HIP_MAX_SORT_KEYS", "10")
+    got = A.arcte(golden["adjacency"], golden["rho"], golden["epsilon"], 1)
+    assert_same_sparse(got, golden["feat1"])

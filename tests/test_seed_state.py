@@ -52,14 +52,16 @@ def test_arcte_state_of_the_production_kernel_equals_the_reference_vectors(name,
     from reveal_graph_embedding_amd import _native
     g = load_golden(name)
     w = g["w"]
-    for hot, lines_lds, indirect in STATE_SPLITS:
+    # (rho = 1e-3 is thousands of pushes per seed, all on the ONE wavefront this entry launches: two splits, six seeds)
+    slow = name == "ba300_rho1e-3"
+    for hot, lines_lds, indirect in (STATE_SPLITS[1:2] + STATE_SPLITS[-1:] if slow else STATE_SPLITS):
         set_split(monkeypatch, hot, lines_lds, indirect)
         with _native.Context(w.indptr, w.indices, w.data, g["out_degree"], g["in_degree"]) as ctx:
             info = ctx.state_info()
             assert info["line_state"] == 1
             if lines_lds is not None and g["n"] > 8 * lines_lds:
                 assert info["lines_region_b"] > 0
-            for k, seed in enumerate(g["seeds"]):
+            for k, seed in enumerate(g["seeds"][:6] if slow else g["seeds"]):
                 tag = "%s seed %d: %d on-chip values, %s lines in LDS, indirect %d" % (name, seed, hot, lines_lds, indirect)
                 # the effective epsilon of the FIXTURE (numpy's logarithms) handed over as is, then the raw epsilon
                 s, r, nop = ctx.seed_state(int(seed), g["rho"], float(g["eps_eff"][k]))
