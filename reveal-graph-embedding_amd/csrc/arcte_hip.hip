@@ -2463,10 +2463,19 @@ int arcte_hip_append_result(arcte_hip_ctx *c, const int64_t *seeds, const int64_
 {
     if (!c || nseeds < 0 || nrows < 0 || (nseeds && (!seeds || !counts)) || (nrows && !rows)) return fail(ARCTE_HIP_EINVAL, "bad argument");
     if (c->run_nseeds < 0) return fail(ARCTE_HIP_ESTATE, "no completed run on this context to append to");
-    if (c->centrality_run) return fail(ARCTE_HIP_ESTATE, "the columns of a centrality run are numbered by a running counter: parts cannot be appended");
     HIP_TRY(hipSetDevice(c->device));
     int64_t sum = 0;
     std::vector<int32_t> s32((size_t)std::max<int64_t>(nseeds, 1));
+    if (c->centrality_run && nseeds) {
+        // arcte.pyx:213-215 numbers the columns by a running counter over the seeds in node order: a part joins a centrality
+        // run only as the NEXT node block (the distributed driver appends the ranks' blocks in rank order)
+        int32_t last = -1;
+        if (c->run_nseeds > 0) HIP_TRY(hipMemcpy(&last, c->seeds_d.p + (c->run_nseeds - 1), sizeof(int32_t), hipMemcpyDeviceToHost));
+        for (int64_t k = 0; k < nseeds; k++) {
+            if (seeds[k] <= (k ? seeds[k - 1] : (int64_t)last))
+                return fail(ARCTE_HIP_EINVAL, "a part appended to a centrality run must continue it in ascending node order");
+        }
+    }
     for (int64_t k = 0; k < nseeds; k++) {
         if (seeds[k] < 0 || seeds[k] >= c->n) return fail(ARCTE_HIP_EINVAL, "seed id out of range");
         if (counts[k] < 0) return fail(ARCTE_HIP_EINVAL, "negative community size");

@@ -86,8 +86,10 @@ def merge_shards(n, seeds, world_size, gathered):
     return sparse.csr_matrix(m)
 
 
-def arcte_distributed(adjacency_matrix, rho, epsilon, device=None, group=None, run_shard=None):
-    """arcte() (arcte.py:591-688) with the seeds sharded over the ranks of `group`.
+def arcte_distributed(adjacency_matrix, rho, epsilon, device=None, group=None, run_shard=None, variant=0):
+    """arcte() (arcte.py:591-688) with the seeds sharded over the ranks of `group`; variant 1 / 2: the PageRank-flavoured
+    drivers arcte_with_pagerank / arcte_with_lazy_pagerank (arcte.py:391-588: the same fan-out over another worker; the
+    lazy flavour hands lazy_rho of arcte.py:109 down, laziness 0.5).
 
     Must be called by every rank with the same adjacency matrix.  Rank 0 returns the n x 2n feature
     matrix, the others None.  Every rank sends its adjacency matrix to its own GPU, where the transition
@@ -113,8 +115,13 @@ def arcte_distributed(adjacency_matrix, rho, epsilon, device=None, group=None, r
         device = int(os.environ.get("LOCAL_RANK", "0"))
     if on_gpu:
         torch.cuda.set_device(device)
+    if variant not in (0, 1, 2):
+        raise ValueError("variant must be 0 (ARCTE), 1 (PageRank) or 2 (lazy PageRank)")
+    run_rho = (rho * 0.5) / (1 - 0.5 * rho) if variant == 2 else rho          # lazy_rho, arcte.py:109
     if run_shard is not None:
-        seeds, colptr, rows = run_shard(adjacency_matrix, rank, world, rho, epsilon)
+        # (a stand-in that is to run another flavour takes it, and the rho the worker would be handed, as keywords)
+        seeds, colptr, rows = (run_shard(adjacency_matrix, rank, world, rho, epsilon) if variant == 0 else
+                               run_shard(adjacency_matrix, rank, world, run_rho, epsilon, variant=variant))
         counts_t = torch.from_numpy(np.diff(colptr).astype(np.int64))
         rows_t = torch.from_numpy(np.ascontiguousarray(rows, dtype=np.int32))
         if on_gpu:
@@ -133,7 +140,7 @@ def arcte_distributed(adjacency_matrix, rho, epsilon, device=None, group=None, r
                                         device=device) as ctx:
         seeds = ctx.seed_list()
         mine = np.sort(shard_seeds(seeds, world, rank))
-        ctx.run_seeds(mine, rho, epsilon, use_effective_epsilon=True)
+        ctx.run_seeds(mine, run_rho, epsilon, use_effective_epsilon=True, variant=variant, laziness_factor=0.5)
         _, total = ctx.result_sizes()
         if on_gpu:
             counts_t = torch.from_numpy(np.diff(ctx.colptr())).to("cuda:%d" % device)
@@ -174,7 +181,6 @@ def arcte_and_centrality_distributed(adjacency_matrix, rho, epsilon, device=None
     import os
     import torch
     import torch.distributed as dist
-    from reveal_graph_embedding_amd.embedding.common import normalize_community_features
 
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
@@ -186,40 +192,66 @@ def arcte_and_centrality_distributed(adjacency_matrix, rho, epsilon, device=None
         device = int(os.environ.get("LOCAL_RANK", "0"))
     if on_gpu:
         torch.cuda.set_device(device)
-    if run_block is not None:
-        colptr, rows, partial = run_block(a, lo, hi, rho, epsilon)
-        w_host = None
-    else:
+    where = "cuda:%d" % device if on_gpu else "cpu"
+
+    def reduce_centrality(partial):
+        cent_t = torch.from_numpy(np.ascontiguousarray(partial, dtype=np.float64)).to(where)
+        dist.all_reduce(cent_t, op=dist.ReduceOp.SUM, group=group)           # the one collective of this driver
+        centrality = cent_t.cpu().numpy()
+        # arcte.pyx:210 ASSIGNS 1.0 to the nodes that were no seeds (no out-edges).  A rank does that inside its own node
+        # block only, while the other ranks' seeds have ADDED s/in_degree to the same node: the rule is applied again to the
+        # sum, on every rank, so that a sink with in-edges ends at 1.0 exactly as in the one-context run.
+        centrality[np.diff(a.indptr) == 0] = 1.0
+        return centrality
+
+    if run_block is None:
+        # HIP path: the context stays open through the gather, and rank 0's context takes the other ranks' node blocks where
+        # the transport left them (arcte_hip_append_result: GPU memory under RCCL, host memory under gloo), assembles
+        # [I + W | local communities] (arcte.pyx:213-228) and normalises it (:238) on its device -- no COO matrix, no hstack
         from reveal_graph_embedding_amd import _native
         with _native.Context.from_adjacency(a.indptr, a.indices, a.data, device=device) as ctx:
             ctx.run_centrality(rho, epsilon, lo, hi)
-            colptr, rows = ctx.fetch()
-            partial = ctx.centrality()
-            w_host = ctx.transition() if rank == 0 else None
-    where = "cuda:%d" % device if on_gpu else "cpu"
-    cent_t = torch.from_numpy(np.ascontiguousarray(partial, dtype=np.float64)).to(where)
-    dist.all_reduce(cent_t, op=dist.ReduceOp.SUM, group=group)           # the one collective of this driver
-    centrality = cent_t.cpu().numpy()
-    # arcte.pyx:210 ASSIGNS 1.0 to the nodes that were no seeds (no out-edges).  A rank does that inside its own node
-    # block only, while the other ranks' seeds have ADDED s/in_degree to the same node: the rule is applied again to the
-    # sum, on every rank, so that a sink with in-edges ends at 1.0 exactly as in the one-context run.
-    centrality[np.diff(a.indptr) == 0] = 1.0
+            centrality = reduce_centrality(ctx.centrality())
+            _, total = ctx.result_sizes()
+            if on_gpu:
+                counts_t = torch.from_numpy(np.diff(ctx.colptr())).to(where)
+                rows_t = torch.empty(total, dtype=torch.int32, device=where)
+                ctx.copy_rows_to_device(rows_t.data_ptr(), total)
+            else:
+                colptr, rows = ctx.fetch()
+                counts_t = torch.from_numpy(np.diff(colptr).astype(np.int64))
+                rows_t = torch.from_numpy(np.ascontiguousarray(rows, dtype=np.int32))
+            gathered = gather_shards(counts_t, rows_t, dst=0, group=group)
+            if rank != 0:
+                return None, centrality
+            has_out = np.diff(a.indptr) > 0                                 # arcte.pyx:165: the seeds are the nodes with out-edges
+            for k in range(1, world):
+                counts_k, rows_k = gathered[k]
+                lo_k, hi_k = k * n // world, (k + 1) * n // world
+                block = np.flatnonzero(has_out[lo_k:hi_k]) + lo_k
+                ctx.append_result(block, counts_k.cpu().numpy(), rows_k.data_ptr(), nrows=rows_k.numel())
+            with _native.Features.from_result(ctx, with_base_block=True) as f:
+                f.normalize_columns().normalize_rows()                      # normalize_community_features, arcte.pyx:238
+                return f.to_scipy(), centrality
+
+    colptr, rows, partial = run_block(a, lo, hi, rho, epsilon)
+    centrality = reduce_centrality(partial)
     counts_t = torch.from_numpy(np.diff(colptr).astype(np.int64)).to(where)
     rows_t = torch.from_numpy(np.ascontiguousarray(rows, dtype=np.int32)).to(where)
     gathered = gather_shards(counts_t, rows_t, dst=0, group=group)
     if rank != 0:
         return None, centrality
+    # (the CPU tests' stand-in for the compute step: what they check is the block split, the all-reduce, the gather and the
+    #  column numbering, merged on the host)
     sizes = np.concatenate([np.asarray(c.cpu().numpy(), dtype=np.int64) for c, _ in gathered])
     members = np.concatenate([np.asarray(r.cpu().numpy(), dtype=np.int64) for _, r in gathered])
     emitted = np.flatnonzero(sizes)
     cols = np.repeat(np.arange(emitted.size), sizes[emitted])             # arcte.pyx:213-215
     local = sparse.coo_matrix((np.ones(members.size), (members, cols)), shape=(n, emitted.size))
-    if w_host is None:
-        w = run_block.transition(a)
-    else:
-        w = sparse.csr_matrix((w_host[2], w_host[1], w_host[0]), shape=(n, n))
+    w = run_block.transition(a)
     base = sparse.csr_matrix(sparse.eye(n, n, dtype=np.float64)) + w      # arcte.pyx:227-228 (see the oracle's note)
     features = sparse.hstack([base, local]).tocsr() if emitted.size else base
-    if run_block is not None and getattr(run_block, "normalize", None) is not None:
+    if getattr(run_block, "normalize", None) is not None:
         return run_block.normalize(features), centrality
+    from reveal_graph_embedding_amd.embedding.common import normalize_community_features
     return normalize_community_features(features, device=device), centrality

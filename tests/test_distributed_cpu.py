@@ -58,6 +58,46 @@ def test_sharded_arcte_equals_reference_fixture(tmp_path, world, name):
     assert_same_sparse(f, load_golden(name)["feat1"])
 
 
+def _variant_worker(rank, world, port, name, tag, out_path):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import oracle
+    from reveal_graph_embedding_amd.distributed import arcte_distributed, shard_seeds
+    g = load_golden(name)
+    variant = {"pr": oracle.PAGERANK, "lazy": oracle.LAZY_PAGERANK}[tag]
+
+    def run_shard(adjacency, rank_, world_, rho, eps, variant=0):
+        # (rho arrives as the worker is handed it: lazy_rho for the lazy flavour; the oracle's worker takes the driver's rho)
+        w, od, idg = oracle.get_natural_random_walk_matrix(adjacency)
+        seeds = oracle.seed_list(adjacency)
+        assert (rho == g["rho"]) == (variant != oracle.LAZY_PAGERANK)
+        colptr, rows = oracle.worker(w, od, idg, shard_seeds(seeds, world_, rank_), g["rho"], eps, variant=variant)
+        return seeds, colptr, rows
+
+    f = arcte_distributed(g["adjacency"], g["rho"], g["epsilon"], run_shard=run_shard, variant=variant)
+    if rank == 0:
+        f.sort_indices()
+        np.savez(out_path, indptr=f.indptr, indices=f.indices, data=f.data, shape=np.array(f.shape))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("tag", ["pr", "lazy"])
+def test_sharded_pagerank_flavours_equal_the_reference_fixtures(tmp_path, tag):
+    """arcte_with_pagerank / arcte_with_lazy_pagerank (reference arcte.py:391-588) over two ranks."""
+    import scipy.sparse as sparse
+    from test_pagerank_variants import load
+    out = str(tmp_path / "f.npz")
+    mp.spawn(_variant_worker, args=(2, _free_port(), "rmat2000", tag, out), nprocs=2, join=True)
+    z = np.load(out)
+    f = sparse.csr_matrix((z["data"], z["indices"], z["indptr"]), shape=tuple(z["shape"]))
+    _, p = load("rmat2000")
+    assert_same_sparse(f, p[tag + "_feat"])
+
+
 def test_shard_seeds_is_the_reference_round_robin():
     from reveal_graph_embedding_amd.distributed import shard_seeds
     from reveal_graph_embedding_amd.embedding.arcte.arcte import parallel_chunks
@@ -68,7 +108,7 @@ def test_shard_seeds_is_the_reference_round_robin():
             assert shard_seeds(seeds, world, k).tolist() == (chunks[k] or [])
 
 
-def _hip_worker(rank, world, port, name, out_path):
+def _hip_worker(rank, world, port, name, out_path, variant=0):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -76,7 +116,7 @@ def _hip_worker(rank, world, port, name, out_path):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from reveal_graph_embedding_amd.distributed import arcte_distributed
     g = load_golden(name)
-    f = arcte_distributed(g["adjacency"], g["rho"], g["epsilon"], device=0)     # both ranks share GPU 0
+    f = arcte_distributed(g["adjacency"], g["rho"], g["epsilon"], device=0, variant=variant)     # both ranks share GPU 0
     if rank == 0:
         f.sort_indices()
         np.savez(out_path, indptr=f.indptr, indices=f.indices, data=f.data, shape=np.array(f.shape))
@@ -93,6 +133,20 @@ def test_sharded_arcte_with_hip_compute_and_gloo_transport(tmp_path):
     z = np.load(out)
     f = sparse.csr_matrix((z["data"], z["indices"], z["indptr"]), shape=tuple(z["shape"]))
     assert_same_sparse(f, load_golden("rmat2000")["feat1"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag,variant", [("pr", 1), ("lazy", 2)])
+def test_sharded_pagerank_flavours_with_hip_compute(tmp_path, tag, variant):
+    """The PageRank-flavoured drivers (reference arcte.py:391-588) process-per-GPU: two ranks, HIP compute, gloo transport."""
+    import scipy.sparse as sparse
+    from test_pagerank_variants import load
+    out = str(tmp_path / "f.npz")
+    mp.spawn(_hip_worker, args=(2, _free_port(), "rmat2000", out, variant), nprocs=2, join=True)
+    z = np.load(out)
+    f = sparse.csr_matrix((z["data"], z["indices"], z["indptr"]), shape=tuple(z["shape"]))
+    _, p = load("rmat2000")
+    assert_same_sparse(f, p[tag + "_feat"])
 
 
 def _centrality_worker(rank, world, port, name, out_path):
