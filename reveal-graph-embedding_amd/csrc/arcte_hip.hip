@@ -3236,7 +3236,7 @@ int arcte_hip_info(arcte_hip_ctx *c, int64_t info[10])
         info[3] = c->cus;
         info[4] = 1;
         info[5] = lines_hot_values(c);
-        info[6] = (c->narrow && (c->tiles == 4 || c->tiles == 2)) ? c->tiles : 1;
+        info[6] = (c->narrow && !c->pack && !c->l_ind && (c->tiles == 4 || c->tiles == 2)) ? c->tiles : 1;      // (what launch_lines_v launches)
         info[7] = c->l_waves_per_cu;
         info[8] = c->pack ? 2 : (c->narrow ? 1 : 0);
         info[9] = 0;

@@ -48,12 +48,37 @@ int io_threads(size_t work_items, size_t per_thread)
 
 bool is_space(unsigned char ch) { return ch == ' ' || ch == '\t' || ch == '\n' || ch == '\r' || ch == '\f' || ch == '\v'; }
 
-// Python's int(field) for the shapes an id takes: optional surrounding whitespace, optional sign, decimal digits
+// PEP 515: int() and float() take single underscores BETWEEN digits ("1_000"); copies the field without them into buf
+// (room for cap bytes), returns the new length or -1 when an underscore stands anywhere else / the field is too long
+int drop_underscores(const char *b, const char *e, char *buf, int cap)
+{
+    int n = 0;
+    for (const char *p = b; p < e; p++) {
+        if (*p == '_') {
+            if (p == b || p + 1 == e || p[-1] < '0' || p[-1] > '9' || p[1] < '0' || p[1] > '9') return -1;
+            continue;
+        }
+        if (n + 1 >= cap) return -1;
+        buf[n++] = *p;
+    }
+    buf[n] = 0;
+    return n;
+}
+
+// Python's int(field) for the shapes an id takes: optional surrounding whitespace, optional sign, decimal digits (single
+// underscores between them)
 bool parse_int(const char *b, const char *e, int64_t &out)
 {
     while (b < e && is_space((unsigned char)*b)) b++;
     while (e > b && is_space((unsigned char)e[-1])) e--;
     if (b == e) return false;
+    char buf[64];
+    if (memchr(b, '_', (size_t)(e - b))) {
+        const int n = drop_underscores(b, e, buf, (int)sizeof(buf));
+        if (n < 0) return false;
+        b = buf;
+        e = buf + n;
+    }
     bool neg = false;
     if (*b == '+' || *b == '-') { neg = *b == '-'; b++; }
     if (b == e) return false;
@@ -68,19 +93,23 @@ bool parse_int(const char *b, const char *e, int64_t &out)
     return true;
 }
 
-// Python's float(field): strtod over the stripped field, all of it
+// Python's float(field): strtod over the stripped field, all of it -- minus what strtod takes and float() does not (hexadecimal
+// floats "0x10", "nan(...)"), plus what float() takes and strtod does not (single underscores between digits).  strtod reads
+// the decimal point of the C locale's LC_NUMERIC; this library never calls setlocale and CPython leaves LC_NUMERIC at "C".
 bool parse_float(const char *b, const char *e, double &out)
 {
     while (b < e && is_space((unsigned char)*b)) b++;
     while (e > b && is_space((unsigned char)e[-1])) e--;
     if (b == e || e - b > 120) return false;
     char buf[128];
-    memcpy(buf, b, (size_t)(e - b));
-    buf[e - b] = 0;
+    const int n = drop_underscores(b, e, buf, (int)sizeof(buf));
+    if (n <= 0) return false;
+    for (int i = 0; i < n; i++)
+        if (buf[i] == 'x' || buf[i] == 'X' || buf[i] == '(') return false;
     char *end = nullptr;
     errno = 0;
     out = strtod(buf, &end);
-    return end == buf + (e - b);
+    return end == buf + n;
 }
 
 struct RawEdge { int64_t src, dst; double w; };
@@ -97,9 +126,16 @@ void parse_chunk(const char *b, const char *e, const std::string &sep, ChunkResu
 {
     const size_t sl = sep.size();
     while (b < e) {
+        // a line ends at "\n", at "\r\n" and at a lone "\r" (the reference iterates a text file: universal newlines)
         const char *nl = (const char *)memchr(b, '\n', (size_t)(e - b));
         const char *le = nl ? nl : e;
         const char *next = nl ? nl + 1 : e;
+        if (const char *cr = (const char *)memchr(b, '\r', (size_t)(le - b))) {
+            if (cr + 1 < le || (cr + 1 == le && !nl)) {      // not the "\r" of a "\r\n": the line ends here
+                le = cr;
+                next = cr + 1;
+            }
+        }
         // line.strip()
         const char *lb = b;
         while (lb < le && is_space((unsigned char)*lb)) lb++;
@@ -247,8 +283,10 @@ int arcte_hip_edge_list_read(const char *path, const char *separator, int undire
     el->col.reserve((size_t)cap);
     el->val.reserve((size_t)cap);
     IdMap map;
+    // (sized from the edge count / 8, not 2x: ids repeat -- a 50M-edge file over 1M nodes would zero-fill 1.6 GB of table and
+    //  probe it at random; get_or_add doubles the table when it fills to one half)
     size_t mcap = 1024;
-    while (mcap < (size_t)std::min<int64_t>(2 * total, (int64_t)1 << 28)) mcap <<= 1;
+    while (mcap < (size_t)std::min<int64_t>(total / 8, (int64_t)1 << 26)) mcap <<= 1;
     map.init(mcap);
     for (int t = 0; t < nt; t++) {
         for (const RawEdge &e : res[(size_t)t].edges) {

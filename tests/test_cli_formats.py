@@ -113,6 +113,39 @@ def test_native_reader_equals_the_reference_loop(tmp_path, separator, undirected
             assert g.dtype == w_.dtype and np.array_equal(g, w_)
 
 
+def test_native_reader_follows_python_number_and_line_rules(tmp_path, monkeypatch):
+    """What int() / float() / text-file iteration take and C's strtod / a split at "\\n" do not, and the other way round
+    (round-3 advisor): single underscores between digits, lines that end in a lone "\\r", hexadecimal floats."""
+    from reveal_graph_embedding_amd import _native
+    from reveal_graph_embedding_amd.datautil.datarw import read_edge_triplets
+    p = tmp_path / "edges.tsv"
+    text = "1_0\t2_000\t1_0.5\r3\t1_0\t2e0\r\n2000\t3\t.5\r#c\r7\t7\t1"
+    p.write_bytes(text.encode())
+    want = _reference_reader(str(p), "\t", True)
+    for threads in ("1", "3"):
+        monkeypatch.setenv("ARCTE_HIP_IO_THREADS", threads)
+        got = read_edge_triplets(str(p), "\t", True)
+        assert got[0] == want[0] == 4
+        for g, w_ in zip(got[1:], want[1:]):
+            assert g.dtype == w_.dtype and np.array_equal(g, w_)
+    for bad in ("1\t2\t0x10\n", "1\t2\t1__0\n", "1\t2\t_1\n", "1\t2\tnan(7)\n", "1_\t2\t1\n", "0x1\t2\t1\n"):
+        p.write_text(bad)
+        with pytest.raises((ValueError, IndexError)):
+            _reference_reader(str(p), "\t", False)                   # the reference's own loop refuses it ...
+        with pytest.raises(_native.ArcteHipError) as e:
+            read_edge_triplets(str(p), "\t", False)                   # ... and so does the native reader
+        assert e.value.code == -1, bad
+    # many distinct ids: the id table starts small and grows
+    rng = np.random.default_rng(11)
+    ids = rng.permutation(200000)
+    p.write_text("".join("%d\t%d\t1\n" % (ids[k], ids[(k * 7 + 1) % ids.size]) for k in range(100000)))
+    want = _reference_reader(str(p), "\t", False)
+    got = read_edge_triplets(str(p), "\t", False)
+    assert got[0] == want[0]
+    for g, w_ in zip(got[1:], want[1:]):
+        assert np.array_equal(g, w_)
+
+
 def test_native_reader_reports_the_bad_line(tmp_path):
     from reveal_graph_embedding_amd import _native
     from reveal_graph_embedding_amd.datautil.datarw import read_edge_triplets
