@@ -538,7 +538,7 @@ LinesLayout lines_layout(const arcte_hip_ctx *c, uint32_t qcap, uint32_t pcap, u
     y.off_queue = o; o += up((size_t)qcap * sizeof(QEntry), 256);
     y.off_sup = o;   o += up((size_t)scap * sizeof(int32_t), 256);
     y.off_ps = o;    o += up((size_t)pcap * sizeof(double2), 256);
-    y.off_gbm = o;   o += up((size_t)(c->l_MB >> 5) * sizeof(uint32_t), 256);
+    y.off_gbm = o;   o += up((size_t)(c->l_ind ? 0 : (c->l_MB >> 5)) * sizeof(uint32_t), 256);      // (indirect lines carry no touched-bits: the entry's generation is the claim)
     const bool pow2 = env_int("ARCTE_HIP_SLOT_POW2", 1) != 0;         // 0: whole 2 MB pages only (A/B)
     const bool split = env_int("ARCTE_HIP_SLOT_SPLIT", 1) != 0;       // 1: region B's values in an allocation of their own (A/B)
     // region B per slot: eight float64 per line, or (indirect lines) an 8-byte entry per line + the pool's lines

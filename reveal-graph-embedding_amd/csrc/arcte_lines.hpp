@@ -61,8 +61,8 @@ struct LineParams {
     uint32_t M, Mshift;           // region A: lines per slot whose touched-bits are in LDS (power of two), log2; ranks < 8 M
     uint32_t MB, MBshift;         // region B (TAIL): lines for the ranks >= 8 M, touched-bits in gbm (0: every rank is in A)
     uint32_t *gbm;                // [slots][MB / 32]
-    // indirect region B (template flag IND): a line of region B lives in the next free line of a per-slot POOL (vals_b), its
-    // place is kept in bidx[line] = seed generation << 32 | pool line; bgen[slot] is the last generation the slot used
+    // indirect region B (template flag IND): a line of region B lives in a line of a per-slot POOL (vals_b), its place is
+    // kept in bidx[line] = seed generation << 32 | ~pool line; bgen[slot] is the last generation the slot used
     uint64_t *bidx;               // [slots][MB]
     uint32_t *bgen;               // [slots]
     uint32_t pool_cap;            // pool lines per slot
@@ -114,18 +114,25 @@ template <int LT> struct LRowT<LT, 2> { bool a[LT]; uint32_t v[LT]; };          
 template <int LT, bool PACK> struct LSlotT { double x[LT]; bool owner[LT]; uint32_t ix[LT]; };
 template <int LT> struct LSlotT<LT, true> { double x[LT]; bool owner[LT]; uint32_t ix[LT]; float dq[LT]; };   // dq: in_degree from the table (escaped lanes)
 template <int LT> struct LPushedT { double2 q[LT]; };
-template <int LT> struct LClaimT { uint32_t old[LT]; uint64_t bi[LT]; };
+template <int LT> struct LClaimT { uint32_t old[LT]; uint64_t bi[LT]; uint32_t base; };   // IND: old = the lane's candidate, bi = the entry before its claim, base = first candidate of the step
 
 // TAIL: the graph has more ranks than the LDS bitmap covers (8 M); the others' lines have their touched-bits in a
 // per-slot bitmap in global memory (L2-resident for graphs of a few million nodes), claimed by a returning atomic OR one
 // pipeline stage before the line is written or read.
 // IND (with TAIL): region B's lines are INDIRECT.  Region B is as large as the graph (8 bytes per node and slot) but a seed
-// touches a few thousand of its lines, so a line that is claimed for the first time takes the next line of a small per-slot
-// pool (a wavefront-private counter: ballot + mbcnt), its owner stores `generation << 32 | pool line` in bidx[line] and
-// writes the pool line blind; later touches read bidx[line] -- ahead of time, with the claim: the entry is valid when its
-// generation is this seed's, which fails only for a line claimed by another lane of the same 64-edge step (then the entry
-// is read again after the owner's store) -- and then the value.  4 MB of bidx per million nodes + the pool instead of
-// 8 MB of values per million nodes; region A, the LDS level and the order of every floating-point operation are unchanged.
+// touches a few thousand of its lines, so a line lives in a line of a small per-slot POOL and an 8-byte ENTRY per line says
+// where: bidx[line] = generation << 32 | ~pool line, valid when it carries the generation of the seed in hand.
+// Round 4 (profiles/r03/region_b_study.txt: 97 % of region B's updates are the first touch of their line): the CLAIM hands out
+// the place.  Every lane that meets region B takes the next candidate pool line (a wavefront-private counter: ballot + mbcnt)
+// and makes ONE returning atomic max of `generation << 32 | ~candidate` on the entry: an entry of an older generation loses
+// (the lane owns the line and writes its candidate blind), an entry of this generation wins over every later candidate
+// (candidates grow, their complements shrink: the entry keeps the FIRST claim's line, whichever lane's atomic arrives first)
+// and tells the lane where the line is.  No touched-bit, no entry read ahead, no entry write, nothing to clear per seed; a
+// non-owner's candidate stays unused (3 % of the claims).  Two lanes of ONE 64-edge step that meet in one line (rare) cannot
+// know which atomic arrived first: whoever sees a place out of this step's candidates calls for the step's region-B lanes
+// to read their entries again when the atomics are done, and the entry decides.  4 MB of entries per million nodes + the pool
+// instead of 8 MB of values per million nodes; region A, the LDS level and the order of every floating-point operation are
+// unchanged.
 template <int MODE, int VAR, int ROWS, bool TAIL, bool PROF = false, int LT = 1, int WPE = 1, bool STAGE = false, bool IND = false>
 __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(WPE))) void k_arcte_lines(PushParams P, LineParams L)
 {
@@ -182,14 +189,18 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(WPE))) voi
     auto value_index = [&](uint32_t rk) -> uint32_t {
         if (in_b(rk)) {
             const uint32_t rp = rk - RA;
-            if constexpr (IND) return RA + (((uint32_t)bidx[rp & MBmask] << 3) | (rp >> MBshift));      // (of a line this seed has claimed)
+            if constexpr (IND) return RA + (((0xFFFFFFFFu - (uint32_t)bidx[rp & MBmask]) << 3) | (rp >> MBshift));      // (of a line this seed has claimed)
             else return RA + (((rp & MBmask) << 3) | (rp >> MBshift));
         }
         return ((rk & Mmask) << 3) | (rk >> Mshift);
     };
     auto val_at = [&](uint32_t ix) -> double * { return (ix < RA ? vals : vals_b) + ix; };     // ix = line * 8 + place; region B's lines follow A's
     auto line_touched = [&](uint32_t rk) -> bool {
-        if (in_b(rk)) { const uint32_t ln = (rk - RA) & MBmask; return (gbm[ln >> 5] >> (ln & 31)) & 1u; }
+        if (in_b(rk)) {
+            const uint32_t ln = (rk - RA) & MBmask;
+            if constexpr (IND) return (uint32_t)(bidx[ln] >> 32) == gen;          // claimed by the seed in hand
+            else return (gbm[ln >> 5] >> (ln & 31)) & 1u;
+        }
         const uint32_t ln = rk & Mmask;
         return (bm[ln >> 5] >> (ln & 31)) & 1u;
     };
@@ -231,7 +242,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(WPE))) voi
         {
             uint64_t *bm64 = reinterpret_cast<uint64_t *>(bm);
             for (uint32_t i = lane; i < (L.M >> 6); i += WAVE) bm64[i] = 0;
-            if (TAIL) {
+            if (TAIL && !IND) {
                 uint4 *g4 = reinterpret_cast<uint4 *>(gbm);
                 for (uint32_t i = lane; i < (L.MB >> 7); i += WAVE) g4[i] = make_uint4(0, 0, 0, 0);
             }
@@ -272,10 +283,25 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(WPE))) voi
                 for (int t = 0; t < LT; t++) {
                     C.old[t] = 0;
                     C.bi[t] = 0;
-                    if (TAIL && R.a[t] && rk_of(R.v[t]) >= RA) {
+                    const bool isb = TAIL && R.a[t] && rk_of(R.v[t]) >= RA;
+                    if constexpr (IND) {
+                        // the claim hands out the place: every lane offers the next candidate pool line, the entry keeps the
+                        // first claim of this generation (see the kernel's header)
+                        const uint64_t mb = __ballot(isb);
+                        if (t == 0) C.base = npool;
+                        uint32_t cand = npool + lane_below(mb);
+                        npool += (uint32_t)__popcll(mb);
+                        if (npool > L.pool_cap) { ok = false; fail_status = ST_POOL_OVERFLOW; }
+                        if (cand >= L.pool_cap) cand = L.pool_cap - 1;          // (the seed fails; nothing may be written outside the pool)
+                        C.old[t] = cand;
+                        if (isb) {
+                            const uint32_t ln = (rk_of(R.v[t]) - RA) & MBmask;
+                            C.bi[t] = atomicMax(reinterpret_cast<unsigned long long *>(&bidx[ln]),
+                                                ((unsigned long long)gen << 32) | (unsigned long long)(0xFFFFFFFFu - cand));
+                        }
+                    } else if (isb) {
                         const uint32_t ln = (rk_of(R.v[t]) - RA) & MBmask;
                         C.old[t] = atomicOr(&gbm[ln >> 5], 1u << (ln & 31));
-                        if constexpr (IND) C.bi[t] = bidx[ln];          // (valid if the line was claimed in an earlier step)
                     }
                 }
             };
@@ -289,7 +315,8 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(WPE))) voi
                     bool owner = false;
                     if (TAIL && line_lvl && rk >= RA) {
                         const uint32_t ln = (rk - RA) & MBmask;
-                        owner = !((C.old[t] >> (ln & 31)) & 1u);
+                        if constexpr (IND) owner = (uint32_t)(C.bi[t] >> 32) != gen;      // the entry was an older seed's: the line is this lane's
+                        else owner = !((C.old[t] >> (ln & 31)) & 1u);
                     } else if (line_lvl) {
                         const uint32_t ln = rk & Mmask;
                         const uint32_t bit = 1u << (ln & 31);
@@ -301,21 +328,20 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(WPE))) voi
                     if constexpr (IND) {
                         const bool isb = line_lvl && rk >= RA;
                         const uint32_t rp = rk - RA, ln = rp & MBmask;
-                        const uint64_t mo = __ballot(isb && owner);
-                        uint32_t pl = (uint32_t)C.bi[t];
-                        if (isb && owner) {
-                            pl = npool + lane_below(mo);
-                            if (pl >= L.pool_cap) pl = L.pool_cap - 1;          // (the seed fails below; nothing may be written outside)
-                            bidx[ln] = ((uint64_t)gen << 32) | pl;
-                        }
-                        npool += (uint32_t)__popcll(mo);
-                        if (npool > L.pool_cap) { ok = false; fail_status = ST_POOL_OVERFLOW; }
-                        // a line claimed by another lane of this very step: the entry read ahead is a stale one
-                        const bool again = isb && !owner && (uint32_t)(C.bi[t] >> 32) != gen;
+                        // owner: its own candidate; otherwise the place the entry named
+                        uint32_t pl = owner ? C.old[t] : 0xFFFFFFFFu - (uint32_t)C.bi[t];
+                        // A place out of THIS step's candidates: another lane of the step met the same line, and which of the two
+                        // atomics arrived first is not ours to know -- the entry is (it keeps the smaller candidate): the step's
+                        // region-B lanes read their entries again, now that the atomics are done, and the entry decides.
+                        const bool again = isb && !owner && pl >= C.base;
                         if (__ballot(again)) {
                             __builtin_amdgcn_s_waitcnt(0x0F70);
-                            if (again) pl = (uint32_t)bidx[ln];
+                            if (isb) {
+                                pl = 0xFFFFFFFFu - (uint32_t)bidx[ln];
+                                owner = pl == C.old[t];
+                            }
                             __builtin_amdgcn_s_waitcnt(0x0F70);
+                            E.owner[t] = owner;
                         }
                         index = isb ? RA + ((pl << 3) | (rp >> MBshift)) : (((rk & Mmask) << 3) | (rk >> Mshift));
                         E.ix[t] = index;
@@ -588,8 +614,8 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(WPE))) voi
             else {
                 if (in_b(sr)) {
                     const uint32_t ln = (sr - RA) & MBmask;
-                    gbm[ln >> 5] |= 1u << (ln & 31);
-                    if constexpr (IND) bidx[ln] = (uint64_t)gen << 32;          // pool line 0
+                    if constexpr (IND) bidx[ln] = ((uint64_t)gen << 32) | 0xFFFFFFFFull;          // pool line 0
+                    else gbm[ln >> 5] |= 1u << (ln & 31);
                 }
                 else { const uint32_t ln = sr & Mmask; bm[ln >> 5] |= 1u << (ln & 31); }
                 const uint32_t ix = value_index(sr), sl = ix & 7u;
