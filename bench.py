@@ -381,7 +381,7 @@ def main():
                 "hot_values_per_wave": info["hot_values_per_wave"], "narrow_rows": info["narrow_rows"],
                 "warm_end_rank": info["warm_end_rank"],
                 "state": {k: state[k] for k in ("line_state", "lines_per_slot", "pushed_capacity", "candidate_capacity", "slot_bytes",
-                                                "bitmap_lds_bytes", "lds_bytes_per_wave", "lines_region_b")},
+                                                "bitmap_lds_bytes", "lds_bytes_per_wave", "lines_region_b", "region_b_indirect", "region_b_pool_lines")},
                 "kernel_source_id": kernel_source_id(),
                 # what the process holds on the device once the context exists: the context's own buffers, the losers of the
                 # slot-memory draw that stay allocated (at most one) and buffers kept from destroyed contexts

@@ -739,8 +739,13 @@ int grow_lines(arcte_hip_ctx *c, bool queue_over, bool pushed_over, bool sup_ove
         scap = std::min<uint32_t>(node_cap, scap * 4);
     }
     if (pool_over) {
-        if (c->l_pool >= c->l_MB) return fail(ARCTE_HIP_ECAPACITY, "region B's pool already holds every line");
-        c->l_pool = std::min<uint32_t>(c->l_MB, c->l_pool * 4);
+        // Every CLAIM of region B takes a pool line, not every line: a claim that finds its line claimed leaves its candidate
+        // unused (3 % of the claims on the graphs region B exists for; nearly all of them on a 2 000-node graph whose region B is
+        // forced).  A pool that outgrows the dense lines has no reason to exist: unless indirect lines were asked for
+        // (ARCTE_HIP_B_INDIRECT=1: the pool keeps growing, to 2^26 lines), the slots get dense lines, which cannot overflow.
+        if (c->l_pool >= (1u << 26)) return fail(ARCTE_HIP_ECAPACITY, "region B's pool cannot grow past 2^26 lines");
+        c->l_pool *= 4;
+        if (c->l_pool > c->l_MB && env_int("ARCTE_HIP_B_INDIRECT", -1) != 1) { c->l_ind = 0; c->l_gen.release(); }
     }
     // (the slot memory changes its shape: losers of the old shape's draw are of no use any more, and left allocated they
     //  would push the device's fill past what setup_lines budgeted for)
