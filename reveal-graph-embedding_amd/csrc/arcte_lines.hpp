@@ -685,7 +685,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(WPE))) voi
                 const unsigned long long t = tick();
                 prof[1] += t - t_mark; t_mark = t; prof[8] += 1;
             }
-            bool fresh = valid;            // r_l is r as of the last push (nothing has been pushed since the batch was read)
+            bool fresh = valid;            // r_l is r as of now (no push since it was read has touched the node)
             LRow PF;                       // the row of entry pf_lane, fetched ahead (rows of one step only)
             double pf_w = 0.0;
             int pf_lane = -1;
@@ -697,7 +697,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(WPE))) voi
                 const double du = shfl_f64(d_l, i);
                 consumed = i + 1;
                 // this entry's pop time is now (similarity.py:204): its r must be the current one -- the node may have been
-                // pushed since it was read (the queue holds duplicates)
+                // pushed or deposited to since it was read (the queue holds duplicates)
                 int32_t ju = __shfl(j_l, i, WAVE);
                 double ru = shfl_f64(r_l, i);
                 if (!__shfl((int)fresh, i, WAVE)) ru = read_r(u, ju);
@@ -707,38 +707,77 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(WPE))) voi
                 }
                 const int64_t rb = shfl_i64(rb_l, i);
                 const int64_t re = shfl_i64(re_l, i);
-                push(u, ju, ru, rb, re, true, pf_lane == i, PF, pf_w);
+                // A row of ONE step (most rows of a sparse graph; 458 pushes per seed on the 8M-node graph, nearly all of them
+                // such rows) is held here, not inside the walk: after the push its targets are compared with the waiting
+                // entries ON CHIP, so that only entries the push touched are read again.  Round 3 read every waiting entry
+                // again after every push: one more dependent round trip per push, 5.3 us per one-step push in all.
+                const bool one_step = re > rb && re - rb <= (int64_t)LT * WAVE;
+                if (one_step && pf_lane != i) {
+                    pf_w = NARROW ? g.data[rb] : 0.0;
+                    load_row(rb, re, pf_w, PF);
+                    pf_lane = i;
+                }
+                const LRow CUR = PF;
+                const double cur_w = pf_w;
+                // the row of the entry that will probably be next (a waiting entry that passes today), fetched while this push
+                // runs: the graph does not change, so the row is right whether or not that entry is pushed in the end
+                LRow NX;
+                double nx_w = 0.0;
+                int nx_lane = -1;
+                {
+                    const uint64_t mn = __ballot(pass && lane >= consumed);
+                    const int nxt = mn ? __ffsll((unsigned long long)mn) - 1 : WAVE;
+                    if (nxt < WAVE) {
+                        const int64_t nb = shfl_i64(rb_l, nxt), ne = shfl_i64(re_l, nxt);
+                        if (ne > nb && ne - nb <= (int64_t)LT * WAVE) {
+                            nx_w = NARROW ? g.data[nb] : 0.0;
+                            load_row(nb, ne, nx_w, NX);
+                            nx_lane = nxt;
+                        }
+                    }
+                }
+                push(u, ju, ru, rb, re, true, one_step, CUR, cur_w);
                 if (VAR == 2) {
                     // similarity.py:136-144: re-push the same node while it stays above the threshold
                     while (ok) {
                         int32_t j2 = -1;
                         const double ru2 = read_r(u, j2);
                         if (!(ru2 / du >= eps)) break;
-                        push(u, j2, ru2, rb, re, false, false, PF, 0.0);
+                        push(u, j2, ru2, rb, re, false, false, CUR, 0.0);          // (the row comes from the cache again: keeping it costs registers)
                     }
                 }
                 if (!ok) break;
-                // One round trip after the push reads again (a) every waiting entry that did not pass -- the push may have
-                // lifted it over the threshold -- and (b) the passing entry whose turn comes next, so that its pop needs no
-                // second look (the other passing entries are read when their turn comes), and (c) fetches that entry's row
-                // ahead when it fits one step: the graph does not change, so the row is right whether or not the entry is
-                // pushed in the end.
-                fresh = false;
-                const uint64_t mp = __ballot(pass && lane >= consumed);
-                const int nxt = mp ? __ffsll((unsigned long long)mp) - 1 : WAVE;
-                pf_lane = -1;
-                if (nxt < WAVE) {
-                    const int64_t nb = shfl_i64(rb_l, nxt), ne = shfl_i64(re_l, nxt);
-                    if (ne > nb && ne - nb <= (int64_t)LT * WAVE) {
-                        pf_w = NARROW ? g.data[nb] : 0.0;
-                        load_row(nb, ne, pf_w, PF);
-                        pf_lane = nxt;
+                // Which waiting entries did the push touch?  The pushed node itself (the queue holds duplicates) and the row's
+                // targets; a row of several steps is not held here: every entry counts as touched, as in round 3.
+                bool touched = true;
+                if (one_step) {
+                    touched = u_l == u;
+#pragma unroll
+                    for (int t = 0; t < LT; t++) {
+                        uint64_t ma = __ballot(CUR.a[t]);
+                        while (ma) {
+                            const int j = __ffsll((unsigned long long)ma) - 1;
+                            ma &= ma - 1;
+                            touched |= u_l == rk_of((uint32_t)__builtin_amdgcn_readlane((int)CUR.v[t], j));
+                        }
                     }
                 }
-                if (valid && lane >= consumed && (!pass || lane == nxt)) {
-                    r_l = read_r(u_l, j_l);
-                    pass = r_l / d_l >= eps;
-                    fresh = true;
+                if (touched) fresh = false;
+                PF = NX;
+                pf_w = nx_w;
+                pf_lane = nx_lane;
+                // One round trip reads again, when there is anything to read: (a) every touched waiting entry that did not pass
+                // -- the push may have lifted it over the threshold -- and (b) the passing entry whose turn comes next, if it
+                // was touched, so that its pop needs no second look (the other passing entries are read when their turn comes).
+                const uint64_t mp = __ballot(pass && lane >= consumed);
+                const int nxt = mp ? __ffsll((unsigned long long)mp) - 1 : WAVE;
+                const bool again = valid && lane >= consumed && !fresh && (!pass || lane == nxt);
+                if (__ballot(again)) {
+                    if (again) {
+                        r_l = read_r(u_l, j_l);
+                        pass = r_l / d_l >= eps;
+                        fresh = true;
+                    }
                 }
             }
         }
