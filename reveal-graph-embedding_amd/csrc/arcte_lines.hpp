@@ -259,6 +259,9 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(WPE))) voi
         int32_t fail_status = ST_QUEUE_OVERFLOW;
         unsigned long long s_lds = 0, s_blind = 0, s_rmw = 0, s_moved = 0;   // this seed's updates by kind (counted when it completes)
 
+        double last_rnew[LT];          // r of every target of the step processed last, as the push left it (one-step rows: forwarded to waiting entries)
+#pragma unroll
+        for (int t = 0; t < LT; t++) last_rnew[t] = 0.0;
         auto load_row = [&](int64_t base, int64_t re, double w_row, LRow &R) {
 #pragma unroll
             for (int t = 0; t < LT; t++) {
@@ -414,6 +417,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(WPE))) voi
                     const double r_old = mv ? ((rk != u) ? Q.q[t].x : r_self) : x;   // a self-loop sees r[u] as just set
                     const double s_old = mv ? ((rk == u && s_self_known) ? s_self : Q.q[t].y) : ((VAR == 0) ? x : 0.0);
                     const double r_new = r_old + p;                                // push.py:64
+                    last_rnew[t] = r_new;
                     const double s_new = (VAR == 0) ? s_old + p : s_old;           // push.py:63 (ARCTE only)
                     if (act) {
                         if (mv) ps[moved_index(x)] = make_double2(r_new, s_new);
@@ -707,73 +711,124 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(WPE))) voi
                 }
                 const int64_t rb = shfl_i64(rb_l, i);
                 const int64_t re = shfl_i64(re_l, i);
-                // A row of ONE step (most rows of a sparse graph; 458 pushes per seed on the 8M-node graph, nearly all of them
-                // such rows) is held here, not inside the walk: after the push its targets are compared with the waiting
-                // entries ON CHIP, so that only entries the push touched are read again.  Round 3 read every waiting entry
-                // again after every push: one more dependent round trip per push, 5.3 us per one-step push in all.
-                const bool one_step = re > rb && re - rb <= (int64_t)LT * WAVE;
-                if (one_step && pf_lane != i) {
-                    pf_w = NARROW ? g.data[rb] : 0.0;
-                    load_row(rb, re, pf_w, PF);
-                    pf_lane = i;
-                }
-                const LRow CUR = PF;
-                const double cur_w = pf_w;
-                // the row of the entry that will probably be next (a waiting entry that passes today), fetched while this push
-                // runs: the graph does not change, so the row is right whether or not that entry is pushed in the end
-                LRow NX;
-                double nx_w = 0.0;
-                int nx_lane = -1;
-                {
-                    const uint64_t mn = __ballot(pass && lane >= consumed);
-                    const int nxt = mn ? __ffsll((unsigned long long)mn) - 1 : WAVE;
+                if constexpr (NARROW) {
+                    // A row of ONE step (most rows of a sparse graph; 458 pushes per seed on the 8M-node graph, nearly all of them
+                    // such rows) is held here, not inside the walk: after the push its targets are compared with the waiting
+                    // entries ON CHIP, so that only entries the push touched are read again.  Round 3 read every waiting entry
+                    // again after every push: one more dependent round trip per push, 5.3 us per one-step push in all.
+                    const bool one_step = re > rb && re - rb <= (int64_t)LT * WAVE;
+                    if (one_step && pf_lane != i) {
+                        pf_w = NARROW ? g.data[rb] : 0.0;
+                        load_row(rb, re, pf_w, PF);
+                        pf_lane = i;
+                    }
+                    const LRow CUR = PF;
+                    const double cur_w = pf_w;
+                    // the row of the entry that will probably be next (a waiting entry that passes today), fetched while this push
+                    // runs: the graph does not change, so the row is right whether or not that entry is pushed in the end
+                    // (wide rows -- weighted graphs -- are five registers per edge: their next row is fetched after the push, as in round 3,
+                    //  or the kernel would lose a wavefront per SIMD)
+                    LRow NX;
+                    double nx_w = 0.0;
+                    int nx_lane = -1;
+                    auto fetch_next = [&]() {
+                        const uint64_t mn = __ballot(pass && lane >= consumed);
+                        const int nxt = mn ? __ffsll((unsigned long long)mn) - 1 : WAVE;
+                        if (nxt < WAVE) {
+                            const int64_t nb = shfl_i64(rb_l, nxt), ne = shfl_i64(re_l, nxt);
+                            if (ne > nb && ne - nb <= (int64_t)LT * WAVE) {
+                                nx_w = NARROW ? g.data[nb] : 0.0;
+                                load_row(nb, ne, nx_w, NX);
+                                nx_lane = nxt;
+                            }
+                        }
+                    };
+                    if constexpr (NARROW) fetch_next();
+                    push(u, ju, ru, rb, re, true, one_step, CUR, cur_w);
+                    if (VAR == 2) {
+                        // similarity.py:136-144: re-push the same node while it stays above the threshold
+                        while (ok) {
+                            int32_t j2 = -1;
+                            const double ru2 = read_r(u, j2);
+                            if (!(ru2 / du >= eps)) break;
+                            push(u, j2, ru2, rb, re, false, false, CUR, 0.0);          // (the row comes from the cache again: keeping it costs registers)
+                        }
+                    }
+                    if (!ok) break;
+                    // Which waiting entries did the push touch?  The pushed node itself (the queue holds duplicates) and the row's
+                    // targets; a row of several steps is not held here: every entry counts as touched, as in round 3.
+                    // A waiting entry that IS a target takes its new r from the lane that computed it (what the push stored: the value in
+                    // the node's place, or PS[j].x of a pushed node) -- no memory round trip; only duplicates of the pushed node itself
+                    // are read again.
+                    bool touched = true;
+                    if (one_step) {
+                        touched = u_l == u;
+                        bool hit = false;
+    #pragma unroll
+                        for (int t = 0; t < LT; t++) {
+                            uint64_t ma = __ballot(CUR.a[t]);
+                            const int lo_ = __double2loint(last_rnew[t]), hi_ = __double2hiint(last_rnew[t]);
+                            while (ma) {
+                                const int j = __ffsll((unsigned long long)ma) - 1;
+                                ma &= ma - 1;
+                                const uint32_t tr = rk_of((uint32_t)__builtin_amdgcn_readlane((int)CUR.v[t], j));
+                                const int flo = __builtin_amdgcn_readlane(lo_, j), fhi = __builtin_amdgcn_readlane(hi_, j);
+                                if (u_l == tr) {
+                                    r_l = __hiloint2double(fhi, flo);
+                                    hit = true;
+                                }
+                            }
+                        }
+                        if (hit && valid) {
+                            pass = r_l / d_l >= eps;
+                            fresh = true;
+                        }
+                    }
+                    if (touched) fresh = false;
+                    if constexpr (!NARROW) fetch_next();
+                    PF = NX;
+                    pf_w = nx_w;
+                    pf_lane = nx_lane;
+                    // One round trip reads again, when there is anything to read: (a) every touched waiting entry that did not pass
+                    // -- the push may have lifted it over the threshold -- and (b) the passing entry whose turn comes next, if it
+                    // was touched, so that its pop needs no second look (the other passing entries are read when their turn comes).
+                    const uint64_t mp = __ballot(pass && lane >= consumed);
+                    const int nxt = mp ? __ffsll((unsigned long long)mp) - 1 : WAVE;
+                    const bool again = valid && lane >= consumed && !fresh && (!pass || lane == nxt);
+                    if (__ballot(again)) {
+                        if (again) {
+                            r_l = read_r(u_l, j_l);
+                            pass = r_l / d_l >= eps;
+                            fresh = true;
+                        }
+                    }
+                } else {
+                    // (wide rows -- weighted graphs, five registers per edge of a row held here -- keep round 3's scheme, or the kernel
+                    //  would lose a wavefront per SIMD: every waiting entry counts as touched by every push, and the next row is
+                    //  fetched in the round trip that reads them again)
+                    push(u, ju, ru, rb, re, true, pf_lane == i, PF, pf_w);
+                    if (VAR == 2) {
+                        while (ok) {
+                            int32_t j2 = -1;
+                            const double ru2 = read_r(u, j2);
+                            if (!(ru2 / du >= eps)) break;
+                            push(u, j2, ru2, rb, re, false, false, PF, 0.0);
+                        }
+                    }
+                    if (!ok) break;
+                    fresh = false;
+                    const uint64_t mp = __ballot(pass && lane >= consumed);
+                    const int nxt = mp ? __ffsll((unsigned long long)mp) - 1 : WAVE;
+                    pf_lane = -1;
                     if (nxt < WAVE) {
                         const int64_t nb = shfl_i64(rb_l, nxt), ne = shfl_i64(re_l, nxt);
                         if (ne > nb && ne - nb <= (int64_t)LT * WAVE) {
-                            nx_w = NARROW ? g.data[nb] : 0.0;
-                            load_row(nb, ne, nx_w, NX);
-                            nx_lane = nxt;
+                            pf_w = 0.0;
+                            load_row(nb, ne, pf_w, PF);
+                            pf_lane = nxt;
                         }
                     }
-                }
-                push(u, ju, ru, rb, re, true, one_step, CUR, cur_w);
-                if (VAR == 2) {
-                    // similarity.py:136-144: re-push the same node while it stays above the threshold
-                    while (ok) {
-                        int32_t j2 = -1;
-                        const double ru2 = read_r(u, j2);
-                        if (!(ru2 / du >= eps)) break;
-                        push(u, j2, ru2, rb, re, false, false, CUR, 0.0);          // (the row comes from the cache again: keeping it costs registers)
-                    }
-                }
-                if (!ok) break;
-                // Which waiting entries did the push touch?  The pushed node itself (the queue holds duplicates) and the row's
-                // targets; a row of several steps is not held here: every entry counts as touched, as in round 3.
-                bool touched = true;
-                if (one_step) {
-                    touched = u_l == u;
-#pragma unroll
-                    for (int t = 0; t < LT; t++) {
-                        uint64_t ma = __ballot(CUR.a[t]);
-                        while (ma) {
-                            const int j = __ffsll((unsigned long long)ma) - 1;
-                            ma &= ma - 1;
-                            touched |= u_l == rk_of((uint32_t)__builtin_amdgcn_readlane((int)CUR.v[t], j));
-                        }
-                    }
-                }
-                if (touched) fresh = false;
-                PF = NX;
-                pf_w = nx_w;
-                pf_lane = nx_lane;
-                // One round trip reads again, when there is anything to read: (a) every touched waiting entry that did not pass
-                // -- the push may have lifted it over the threshold -- and (b) the passing entry whose turn comes next, if it
-                // was touched, so that its pop needs no second look (the other passing entries are read when their turn comes).
-                const uint64_t mp = __ballot(pass && lane >= consumed);
-                const int nxt = mp ? __ffsll((unsigned long long)mp) - 1 : WAVE;
-                const bool again = valid && lane >= consumed && !fresh && (!pass || lane == nxt);
-                if (__ballot(again)) {
-                    if (again) {
+                    if (valid && lane >= consumed && (!pass || lane == nxt)) {
                         r_l = read_r(u_l, j_l);
                         pass = r_l / d_l >= eps;
                         fresh = true;
