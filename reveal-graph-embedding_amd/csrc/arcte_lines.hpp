@@ -779,10 +779,8 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(WPE))) voi
                                 }
                             }
                         }
-                        if (hit && valid) {
-                            pass = r_l / d_l >= eps;
-                            fresh = true;
-                        }
+                        // (an entry that was stale stays stale: its place in PS may have changed too, which only a read tells)
+                        if (hit && valid) pass = r_l / d_l >= eps;
                     }
                     if (touched) fresh = false;
                     if constexpr (!NARROW) fetch_next();
