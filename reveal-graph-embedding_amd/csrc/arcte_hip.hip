@@ -742,10 +742,11 @@ int grow_lines(arcte_hip_ctx *c, bool queue_over, bool pushed_over, bool sup_ove
         // Every CLAIM of region B takes a pool line, not every line: a claim that finds its line claimed leaves its candidate
         // unused (3 % of the claims on the graphs region B exists for; nearly all of them on a 2 000-node graph whose region B is
         // forced).  A pool that outgrows the dense lines has no reason to exist: unless indirect lines were asked for
-        // (ARCTE_HIP_B_INDIRECT=1: the pool keeps growing, to 2^26 lines), the slots get dense lines, which cannot overflow.
+        // (ARCTE_HIP_B_INDIRECT=1: the pool keeps growing, to 2^26 lines), slots whose pool passes TWICE the dense lines get dense
+        // lines, which cannot overflow.
         if (c->l_pool >= (1u << 26)) return fail(ARCTE_HIP_ECAPACITY, "region B's pool cannot grow past 2^26 lines");
         c->l_pool *= 4;
-        if (c->l_pool > c->l_MB && env_int("ARCTE_HIP_B_INDIRECT", -1) != 1) { c->l_ind = 0; c->l_gen.release(); }
+        if (c->l_pool > 2 * (uint64_t)c->l_MB && env_int("ARCTE_HIP_B_INDIRECT", -1) != 1) { c->l_ind = 0; c->l_gen.release(); }
     }
     // (the slot memory changes its shape: losers of the old shape's draw are of no use any more, and left allocated they
     //  would push the device's fill past what setup_lines budgeted for)
@@ -1153,8 +1154,12 @@ int setup_lines(arcte_hip_ctx *c, uint32_t M)
     // region B dense (8 bytes per node and slot) or indirect (8 bytes per LINE + a pool of lines: arcte_lines.hpp, IND)?
     // ARCTE_HIP_B_INDIRECT = 1 / 0 decides; by default (below) indirect only when the dense region would cost wavefronts
     {
+        // Round 4, with the claim that hands out the pool line (ms per launch, dense against indirect, one box each: n = 4M 2 314 /
+        // 2 339 with 129 / 52 GB of slot memory; n = 8M 4 574 / 4 256 with 193 / 58 GB; n = 16M: dense does not fit twelve wavefronts
+        // per CU): indirect from 16 MB of dense region B per slot on (n > ~2.5 M), dense below (n = 1M: 4 MB per slot).
         const int want = env_int("ARCTE_HIP_B_INDIRECT", -1);
-        c->l_ind = c->l_MB > 0 && want == 1;
+        const size_t dense_b = ((size_t)c->l_MB << 3) * sizeof(double);
+        c->l_ind = c->l_MB > 0 && (want == 1 || (want < 0 && dense_b >= ((size_t)std::max(1, env_int("ARCTE_HIP_B_INDIRECT_MIN_MB", 16)) << 20)));
         c->l_pool = std::min<uint32_t>(c->l_MB, (uint32_t)std::max(64, env_int("ARCTE_HIP_B_POOL", 32768)));
     }
     int64_t slots = c->want_slots;
@@ -2015,7 +2020,7 @@ static int run_seeds_impl(arcte_hip_ctx *c, const int64_t *seeds, int64_t nseeds
         bool queue_over = false, out_over = false, contrib_over = false, pushed_over = false, sup_over = false, pool_over = false;
         int64_t add = 0;
         std::vector<int32_t> by_pos(work);
-        std::sort(by_pos.begin(), by_pos.end());
+        if (!std::is_sorted(by_pos.begin(), by_pos.end())) std::sort(by_pos.begin(), by_pos.end());      // (the first launch lists every position in order)
         for (int32_t pos : by_pos) {
             const int32_t st = status_h[pos];
             dst_h[pos] = final_used + add;
