@@ -641,6 +641,9 @@ int draw_slot_memory(arcte_hip_ctx *c, size_t slots, size_t block)
             // (packed slots: two classes, 20 and 24 -- a fast one in hand is enough; spread slots have a top level at 26 that a
             //  20 / 24 pair does not show yet)
             if (c->placement_probe[(size_t)best] >= (c->l_spread ? 1.25 : 1.1) * slowest) break;
+            // (spread slots: a candidate on the top level -- 25 G updates/s and more on every box so far, the levels below are 20, 22 and 24 --
+            //  ends the draw at once: one allocation, nothing parked, no further hipMalloc on boxes where those take seconds)
+            if (c->l_spread && c->placement_probe[(size_t)best] >= 0.1 * std::max(1, env_int("ARCTE_HIP_DRAW_GOOD_X10", 250))) break;
             if (known_best > 0.0 && c->placement_probe[(size_t)best] >= 0.97 * known_best) break;   // as good as this process has seen
         }
         if (best < 0) return fail(ARCTE_HIP_EHIP, "no memory for the propagation slots");

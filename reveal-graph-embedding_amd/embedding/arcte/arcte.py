@@ -139,6 +139,9 @@ def _features_of_run(ctx, variant, iterate_nodes, rho, epsilon, with_base_block,
         # Large runs go in TWO launches: every eighth seed first (the list's own mix: its emitted rows times eight size the
         # result within a per cent), then the others -- and while those run, background threads allocate, fill and fault in the
         # host arrays the result will land in.  The device assembly + copy-out that follows finds touched pages.
+        import time
+        verbose = bool(os.environ.get("ARCTE_HIP_VERBOSE"))
+        t0 = time.perf_counter()
         sizing = iterate_nodes[::_SIZING_STRIDE]
         keep = np.ones(iterate_nodes.size, dtype=bool)
         keep[::_SIZING_STRIDE] = False
@@ -147,16 +150,24 @@ def _features_of_run(ctx, variant, iterate_nodes, rho, epsilon, with_base_block,
         _, rows_first = ctx.result_sizes()
         base_entries = ctx.result_csr_size(with_base_block) - rows_first
         estimate = base_entries + int(rows_first * (iterate_nodes.size / max(sizing.size, 1)) * 1.04) + (1 << 20)
+        t1 = time.perf_counter()
         host = _HostArraysInBackground(estimate)
         try:
             ctx.run_seeds(iterate_nodes[keep], rho, epsilon, use_effective_epsilon=True, variant=variant,
                           laziness_factor=laziness_factor, append=True)
+            t2 = time.perf_counter()
         finally:
             host.wait()
+        t3 = time.perf_counter()
         nnz = ctx.result_csr_size(with_base_block)
         if nnz <= host.capacity:
             try:
                 indptr, indices = ctx.fetch_csr(with_base_block, out_indices=host.indices)
+                if verbose:
+                    import sys
+                    print("[arcte] sizing part %.3f s, the rest %.3f s, waited %.3f s for the host arrays (%d entries, estimate %d), "
+                          "device assembly + copy-out %.3f s" % (t1 - t0, t2 - t1, t3 - t2, nnz, host.capacity, time.perf_counter() - t3),
+                          file=sys.stderr, flush=True)
             except _native.ArcteHipError as e:
                 if e.code != -3:                  # ARCTE_HIP_ECAPACITY: too many entries for the device assembly
                     raise
@@ -288,9 +299,18 @@ def _arcte_driver(adjacency_matrix, rho, epsilon, number_of_threads, worker):
         ones.data = np.ones_like(ones.data, dtype=np.float64)
         return ones
 
-    def self_loops():
+    def find_self_loops():
         row_of = np.repeat(np.arange(number_of_nodes), np.diff(adjacency_matrix.indptr))
         return row_of[adjacency_matrix.indices == row_of]
+
+    # (0.2 s of numpy on the 1M-node graph, off the critical path: it runs while the GPU does)
+    loops_box = []
+    loops_thread = threading.Thread(target=lambda: loops_box.append(find_self_loops()))
+    loops_thread.start()
+
+    def self_loops():
+        loops_thread.join()
+        return loops_box[0]
 
     # The adjacency matrix goes to the GPU as it is: the transition matrix, both degree vectors and the seed list
     # (arcte.py:608-617) are made there (arcte_hip_create_from_adjacency) and never come back.
