@@ -125,6 +125,18 @@ std::vector<BigCacheEntry> g_big_cache;
 // returned by arcte_hip_trim() and whenever an allocation fails.  g_best_probe: the fastest probe rate seen per
 // (device, size) in this process -- a candidate that reaches it is taken at once.
 std::vector<BigCacheEntry> g_parked;
+// line-state contexts of this process alive per device: a context that SHARES its GPU (several workers on one device) takes
+// packed slots and the first allocation it gets -- drawing candidates of tens of GB beside another context's slots is what
+// made three workers on one GPU 2.3x slower than one (profiles/r04/multi_worker_1m.txt, first record)
+std::vector<int> g_live_lines_devices;
+int live_line_contexts_on(int device)
+{
+    // (g_big_mutex is declared above)
+    std::lock_guard<std::mutex> lock(g_big_mutex);
+    int k = 0;
+    for (int d : g_live_lines_devices) k += d == device;
+    return k;
+}
 struct BestProbe { int device; size_t bytes; double rate; };
 std::vector<BestProbe> g_best_probe;
 
@@ -335,6 +347,7 @@ struct arcte_hip_ctx {
     int64_t line_stats[4] = {0, 0, 0, 0};   // last run: LDS updates, blind line writes, read-modify-writes, updates of pushed nodes
     std::vector<double> placement_probe;    // G updates/s of every candidate allocation of the slot memory, in draw order
     int placement_kept = -1;
+    int registered = 0;                     // counted in g_live_lines_devices
     DevBuf<double> dump_s, dump_r;          // arcte_hip_seed_state: the one seed's dense s and r (LineParams::dump_s)
     int dump_on = 0;
     // per-run
@@ -569,7 +582,7 @@ size_t lines_bytes_per_slot(const arcte_hip_ctx *c, uint32_t qcap, uint32_t pcap
 
 // The slot memory's placement decides the propagation kernel's speed (two main levels 23 % apart),
 // and hipMalloc leaves it to chance.  So a context that is large enough to care draws up to ARCTE_HIP_PLACEMENT_TRIES (8;
-// ARCTE_HIP_SPREAD_TRIES = 3 of the much larger spread layout) candidate allocations -- alive at the same time, so that
+// ARCTE_HIP_SPREAD_TRIES = 2 of the much larger spread layout: a third 51.5 GB hipMalloc took 2.7 s on two boxes of round 4) candidate allocations -- alive at the same time, so that
 // they are different memory --, runs k_probe_slots on each (a few milliseconds of the kernel's own access pattern) and
 // keeps the fastest; the others are parked (g_parked).  The probe sees levels of memory (20, 22, 24 and 26 G updates/s
 // on the 1M/50M graph's slots; the push kernel runs 93 / 85 / 78 / 72 ms per 81 434 seeds on them): the draw stops as
@@ -585,11 +598,12 @@ int draw_slot_memory(arcte_hip_ctx *c, size_t slots, size_t block)
     if (bytes < ((size_t)std::max(1, env_int("ARCTE_HIP_PLACEMENT_MIN_MB", 1024)) << 20) || slots < 256 ||
         c->n < (int64_t)env_int("ARCTE_HIP_PLACEMENT_MIN_NODES", 262144))
         tries = 1;
+    if (live_line_contexts_on(c->device) > (c->registered ? 1 : 0)) tries = 1;          // the device is shared: see g_live_lines_devices
     if (tries == 1) {
         HIP_TRY(c->l_block.alloc(bytes, c->device));
         return 0;
     }
-    if (c->l_spread) tries = std::min(tries, std::max(1, env_int("ARCTE_HIP_SPREAD_TRIES", 3)));      // (candidates of 50 GB and more)
+    if (c->l_spread) tries = std::min(tries, std::max(1, env_int("ARCTE_HIP_SPREAD_TRIES", 2)));      // (candidates of 50 GB and more)
     free_parked_on(c->device, bytes);          // losers of a draw of another shape: of no use to this one
     // A draw may cost this much allocation time before it settles for what it holds (on some boxes a hipMalloc of tens of
     // GB takes a second or more, profiles/r03/first_call_1m.txt: there the third candidate is not worth its price)
@@ -1136,6 +1150,11 @@ int ensure_dense(arcte_hip_ctx *c, bool full)
 int setup_lines(arcte_hip_ctx *c, uint32_t M)
 {
     const int64_t n = c->n;
+    if (!c->registered) {
+        std::lock_guard<std::mutex> lock(g_big_mutex);
+        g_live_lines_devices.push_back(c->device);
+        c->registered = 1;
+    }
     c->l_M = M;
     c->l_Mshift = 0;
     while ((1u << c->l_Mshift) < M) c->l_Mshift++;
@@ -1194,6 +1213,7 @@ int setup_lines(arcte_hip_ctx *c, uint32_t M)
         c->l_spread = 0;
         const int spread_mb = env_int("ARCTE_HIP_SLOT_SPREAD_MB", 16);
         if (spread_mb <= 0 || slots < 256 || n < (int64_t)env_int("ARCTE_HIP_PLACEMENT_MIN_NODES", 262144)) return;
+        if (live_line_contexts_on(c->device) > (c->registered ? 1 : 0)) return;          // a shared device: packed slots
         c->l_spread = 1;                                          // (1: behind one another without padding)
         const size_t needed = lines_bytes_per_slot(c, qcap, pcap, scap);
         size_t stride = (size_t)spread_mb << 20;
@@ -1700,6 +1720,12 @@ int arcte_hip_destroy(arcte_hip_ctx *c)
     if (!c) return 0;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->registered) {
+        std::lock_guard<std::mutex> lock(g_big_mutex);
+        for (size_t i = 0; i < g_live_lines_devices.size(); i++)
+            if (g_live_lines_devices[i] == c->device) { g_live_lines_devices.erase(g_live_lines_devices.begin() + (long)i); break; }
+        c->registered = 0;
+    }
     c->indptr.release(); c->indices.release(); c->data.release(); c->out_degree.release(); c->in_degree.release();
     release_cached(c->state, c->device); release_cached(c->sup, c->device); release_cached(c->queue, c->device); release_cached(c->warm, c->device);
     release_cached(c->contrib_key, c->device); release_cached(c->contrib_val, c->device);
