@@ -316,9 +316,16 @@ def main():
             h.update(np.asarray(v_indices, dtype=np.int64).tobytes())
             merged_sha = h.hexdigest()
         ctx.run_seeds(parts[-1], run_rho, args.epsilon, use_effective_epsilon=True, variant=variant)   # (the fetch below times a part)
+    # D2H of the step's result: reported beside the metric, never inside it.  Twice: into a fresh numpy array (its pages are
+    # faulted in by the copy itself: tools/d2h_rate.hip, 11.6 GB/s) and into that same array again (touched pages: what a caller
+    # that reuses its result buffer -- or faults it in while the GPU runs, as arcte() does -- pays)
     t = time.perf_counter()
-    ctx.fetch()                      # D2H of the step's result: reported beside the metric, never inside it
+    _, rows_host = ctx.fetch()
+    fetch_cold_ms = (time.perf_counter() - t) * 1e3
+    t = time.perf_counter()
+    ctx.fetch(out_rows=rows_host)
     fetch_ms = (time.perf_counter() - t) * 1e3
+    del rows_host
     if rank == 0:
         alg = algorithmic_bytes(st)
         alg_push_only = 52 * st["edges"] + 36 * st["pushes"]          # "the eps-push-kernel-only figure"
@@ -399,7 +406,7 @@ def main():
                 "per_seed": {k: st[k] / max(shard.size, 1) for k in ("pushes", "edges", "enqueues", "support", "candidates")},
                 "reruns": st["reruns"],
                 "eps_kernel_ms": tm["eps_ms"], "compact_ms": tm["compact_ms"], "call_ms": tm["call_ms"],
-                "result_d2h_ms_rank0": fetch_ms,
+                "result_d2h_ms_rank0": fetch_ms, "result_d2h_into_untouched_pages_ms_rank0": fetch_cold_ms,
                 "pcie_inclusive_seeds_per_s_rank0": shard.size / ((elapsed / max(args.steps, 1)) + fetch_ms * 1e-3),
             },
             "roofline": {

@@ -361,10 +361,18 @@ class Context:
         _check(lib().arcte_hip_result_sizes(self._h, C.byref(ns), C.byref(tot)))
         return ns.value, tot.value
 
-    def fetch(self, want_eps=False, want_nop=False):
+    def fetch(self, want_eps=False, want_nop=False, out_rows=None):
+        """(colptr, rows[, eps][, nop]) of the last run.  out_rows: a C-contiguous int32 array of at least result_sizes()[1]
+        entries to receive the rows (a buffer a caller reuses has its pages faulted in: the copy then runs at the PCIe rate
+        instead of a fifth of it)."""
         ns, tot = self.result_sizes()
         colptr = np.zeros(ns + 1, dtype=np.int64)
-        rows = np.zeros(tot, dtype=np.int32)
+        if out_rows is not None:
+            if out_rows.dtype != np.int32 or not out_rows.flags.c_contiguous or out_rows.size < tot:
+                raise ValueError("out_rows must be a C-contiguous int32 array of at least %d entries" % tot)
+            rows = out_rows[:tot]
+        else:
+            rows = np.zeros(tot, dtype=np.int32)
         eps = np.zeros(ns, dtype=np.float64) if want_eps else None
         nop = np.zeros(ns, dtype=np.int64) if want_nop else None
         _check(lib().arcte_hip_fetch_result(

@@ -18,7 +18,7 @@ python - <<PY
 import json, glob, os
 O = "$O"
 for f in ("r04_shard_of_8_sub4.json", "r04_shard_of_8_sub1.json"):
-    d = json.load(open(os.path.join(O, f)))
+    d = json.loads([l for l in open(os.path.join(O, f)) if l.startswith("{")][-1])
     k = d["roofline"]["kernel_ms_per_launch"]
     print(f, "ms_per_step %.2f  kernel ms per step %.2f  host share %.3f  seeds/step %d  sub-launches %d" % (
         d["ms_per_step"], k, 1 - k / d["ms_per_step"], d["config"]["seeds_per_step"], d["config"]["sub_launches"]))
