@@ -582,7 +582,7 @@ size_t lines_bytes_per_slot(const arcte_hip_ctx *c, uint32_t qcap, uint32_t pcap
 
 // The slot memory's placement decides the propagation kernel's speed (two main levels 23 % apart),
 // and hipMalloc leaves it to chance.  So a context that is large enough to care draws up to ARCTE_HIP_PLACEMENT_TRIES (8;
-// ARCTE_HIP_SPREAD_TRIES = 2 of the much larger spread layout: a third 51.5 GB hipMalloc took 2.7 s on two boxes of round 4) candidate allocations -- alive at the same time, so that
+// ARCTE_HIP_SPREAD_TRIES = 4 of the much larger spread layout, of which the third and fourth are drawn only while every candidate so far sits on the slow level) candidate allocations -- alive at the same time, so that
 // they are different memory --, runs k_probe_slots on each (a few milliseconds of the kernel's own access pattern) and
 // keeps the fastest; the others are parked (g_parked).  The probe sees levels of memory (20, 22, 24 and 26 G updates/s
 // on the 1M/50M graph's slots; the push kernel runs 93 / 85 / 78 / 72 ms per 81 434 seeds on them): the draw stops as
@@ -603,11 +603,12 @@ int draw_slot_memory(arcte_hip_ctx *c, size_t slots, size_t block)
         HIP_TRY(c->l_block.alloc(bytes, c->device));
         return 0;
     }
-    if (c->l_spread) tries = std::min(tries, std::max(1, env_int("ARCTE_HIP_SPREAD_TRIES", 2)));      // (candidates of 50 GB and more)
+    if (c->l_spread) tries = std::min(tries, std::max(1, env_int("ARCTE_HIP_SPREAD_TRIES", 4)));      // (candidates of 50 GB and more)
     free_parked_on(c->device, bytes);          // losers of a draw of another shape: of no use to this one
     // A draw may cost this much allocation time before it settles for what it holds (on some boxes a hipMalloc of tens of
     // GB takes a second or more, profiles/r03/first_call_1m.txt: there the third candidate is not worth its price)
     const double alloc_budget_s = std::max(0, env_int("ARCTE_HIP_DRAW_ALLOC_MS", 400)) * 1e-3;
+    const double level_good = 0.1 * std::max(1, env_int("ARCTE_HIP_DRAW_GOOD_X10", 250)), level_ok = 0.1 * std::max(1, env_int("ARCTE_HIP_DRAW_OK_X10", 230));
     double alloc_spent_s = 0.0;
     std::vector<SlotMem> cand((size_t)tries);
     DevBuf<unsigned long long> sink;
@@ -629,7 +630,9 @@ int draw_slot_memory(arcte_hip_ctx *c, size_t slots, size_t block)
                 size_t free_b = 0, total_b = 0;
                 HIP_TRY(hipMemGetInfo(&free_b, &total_b));
                 if (free_b + cached_bytes_on(c->device) < bytes + bytes / 2 + ((size_t)24 << 30)) break;      // no room for another candidate
-                if (alloc_spent_s > alloc_budget_s) break;
+                // (the allocation-time budget ends a draw that holds a candidate off the slow level; a draw that holds only slow
+                //  ones goes on -- 750 against 590-630 ms per launch is worth seconds of hipMalloc)
+                if (alloc_spent_s > alloc_budget_s && best >= 0 && c->placement_probe[(size_t)best] >= level_ok) break;
             }
             const auto ta = std::chrono::steady_clock::now();
             if (cand[(size_t)t].alloc(bytes, c->device) != hipSuccess) { (void)hipGetLastError(); cand[(size_t)t].release(c->device); break; }
@@ -654,10 +657,16 @@ int draw_slot_memory(arcte_hip_ctx *c, size_t slots, size_t block)
             const double slowest = *std::min_element(c->placement_probe.begin(), c->placement_probe.end());
             // (packed slots: two classes, 20 and 24 -- a fast one in hand is enough; spread slots have a top level at 26 that a
             //  20 / 24 pair does not show yet)
-            if (c->placement_probe[(size_t)best] >= (c->l_spread ? 1.25 : 1.1) * slowest) break;
-            // (spread slots: a candidate on the top level -- 25 G updates/s and more on every box so far, the levels below are 20, 22 and 24 --
-            //  ends the draw at once: one allocation, nothing parked, no further hipMalloc on boxes where those take seconds)
-            if (c->l_spread && c->placement_probe[(size_t)best] >= 0.1 * std::max(1, env_int("ARCTE_HIP_DRAW_GOOD_X10", 250))) break;
+            if (!c->l_spread && c->placement_probe[(size_t)best] >= 1.1 * slowest) break;
+            // Spread slots: the probe's levels are 20, 22, 24 and 26 G updates/s on every box so far (the push kernel: ~750, 680, 630 and
+            // 590 ms per launch of the 1M/50M graph).  A candidate on the top level ends the draw at once (one allocation, nothing
+            // parked); from the SECOND candidate on the 24 level is good enough (a third 51.5 GB hipMalloc took 2.7 s on two boxes of
+            // round 4: profiles/r04/first_call_1m.txt); a draw that holds nothing but the slow level goes on to ARCTE_HIP_SPREAD_TRIES
+            // candidates (4): two slow candidates in a row happened in one of eleven round-4 processes (0.296 instead of 0.35-0.38).
+            if (c->l_spread) {
+                if (c->placement_probe[(size_t)best] >= level_good) break;
+                if (t >= 1 && c->placement_probe[(size_t)best] >= level_ok) break;
+            }
             if (known_best > 0.0 && c->placement_probe[(size_t)best] >= 0.97 * known_best) break;   // as good as this process has seen
         }
         if (best < 0) return fail(ARCTE_HIP_EHIP, "no memory for the propagation slots");
