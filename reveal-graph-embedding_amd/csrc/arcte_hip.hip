@@ -660,12 +660,14 @@ int draw_slot_memory(arcte_hip_ctx *c, size_t slots, size_t block)
             if (!c->l_spread && c->placement_probe[(size_t)best] >= 1.1 * slowest) break;
             // Spread slots: the probe's levels are 20, 22, 24 and 26 G updates/s on every box so far (the push kernel: ~750, 680, 630 and
             // 590 ms per launch of the 1M/50M graph).  A candidate on the top level ends the draw at once (one allocation, nothing
-            // parked); from the SECOND candidate on the 24 level is good enough (a third 51.5 GB hipMalloc took 2.7 s on two boxes of
-            // round 4: profiles/r04/first_call_1m.txt); a draw that holds nothing but the slow level goes on to ARCTE_HIP_SPREAD_TRIES
-            // candidates (4): two slow candidates in a row happened in one of eleven round-4 processes (0.296 instead of 0.35-0.38).
+            // parked).  Below it the draw goes on to a THIRD candidate -- of the round-4 draws that took three, the third sat on the top
+            // level in eleven of twenty-one (a later allocation lands there more often than the first) -- at the price of a third
+            // hipMalloc of 51.5 GB, which took 2.7 s on two boxes; from the third candidate on the 24 level is good enough, and only a
+            // draw that holds nothing but the slow level goes on to ARCTE_HIP_SPREAD_TRIES (4) candidates: two slow candidates in a row
+            // happened in one of eleven round-4 processes (0.296 instead of 0.35-0.38).
             if (c->l_spread) {
                 if (c->placement_probe[(size_t)best] >= level_good) break;
-                if (t >= 1 && c->placement_probe[(size_t)best] >= level_ok) break;
+                if (t >= 2 && c->placement_probe[(size_t)best] >= level_ok) break;
             }
             if (known_best > 0.0 && c->placement_probe[(size_t)best] >= 0.97 * known_best) break;   // as good as this process has seen
         }
