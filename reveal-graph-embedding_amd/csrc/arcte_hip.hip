@@ -125,56 +125,29 @@ std::vector<BigCacheEntry> g_big_cache;
 // returned by arcte_hip_trim() and whenever an allocation fails.  g_best_probe: the fastest probe rate seen per
 // (device, size) in this process -- a candidate that reaches it is taken at once.
 std::vector<BigCacheEntry> g_parked;
-// line-state contexts of this process alive per device: a context that SHARES its GPU (several workers on one device) takes
-// packed slots and the first allocation it gets -- drawing candidates of tens of GB beside another context's slots is what
-// made three workers on one GPU 2.3x slower than one (profiles/r04/multi_worker_1m.txt, first record)
-std::vector<int> g_live_lines_devices;
-int live_line_contexts_on(int device)
-{
-    // (g_big_mutex is declared above)
-    std::lock_guard<std::mutex> lock(g_big_mutex);
-    int k = 0;
-    for (int d : g_live_lines_devices) k += d == device;
-    return k;
-}
-struct BestProbe { int device; size_t bytes; double rate; };
-std::vector<BestProbe> g_best_probe;
-
-bool free_parked_buffers()
+// line-state contexts of this process alive per device, with the slot memory they plan to hold: a context that SHARES its
+// GPU with another LARGE one (several workers on one device) takes packed slots and the first allocation it gets -- drawing
+// candidates of tens of GB beside another context's slots is what made three workers on one GPU 2.3x slower than one
+// (profiles/r04/multi_worker_1m.txt, first record).  Small contexts (a forgotten handle of a test graph) do not count.
+struct LiveLines { int device; const void *ctx; size_t planned; };
+std::vector<LiveLines> g_live_lines;
+// registers ctx's plan and says whether another context of this device plans (or holds) 1 GB of slot memory or more
+bool plan_slot_memory(int device, const void *ctx, size_t planned)
 {
     std::lock_guard<std::mutex> lock(g_big_mutex);
-    const bool any = !g_parked.empty();
-    int current = 0;
-    const bool have_current = hipGetDevice(&current) == hipSuccess;
-    for (auto &e : g_parked) {
-        (void)hipSetDevice(e.device);
-        (void)hipFree(e.p);
+    bool shared = false, found = false;
+    for (auto &e : g_live_lines) {
+        if (e.ctx == ctx) { e.planned = planned; found = true; }
+        else if (e.device == device && e.planned >= ((size_t)1 << 30)) shared = true;
     }
-    g_parked.clear();
-    if (any && have_current) (void)hipSetDevice(current);        // (the caller's allocation goes on)
-    return any;
+    if (!found) g_live_lines.push_back({device, ctx, planned});
+    return shared;
 }
-
-// the parked buffers of one device: all of them, or (keep_bytes > 0) those of any other size -- a draw of another shape
-// has no use for them and they would sit on memory the new slots want
-void free_parked_on(int device, size_t keep_bytes = 0)
+void forget_slot_memory_plan(const void *ctx)
 {
     std::lock_guard<std::mutex> lock(g_big_mutex);
-    for (size_t i = 0; i < g_parked.size();) {
-        if (g_parked[i].device == device && (keep_bytes == 0 || g_parked[i].bytes != keep_bytes)) {
-            (void)hipFree(g_parked[i].p);          // (callers have set the device)
-            g_parked.erase(g_parked.begin() + (long)i);
-        } else i++;
-    }
-}
-
-size_t parked_bytes_on(int device)
-{
-    std::lock_guard<std::mutex> lock(g_big_mutex);
-    size_t b = 0;
-    for (const auto &e : g_parked)
-        if (e.device == device) b += e.bytes;
-    return b;
+    for (size_t i = 0; i < g_live_lines.size(); i++)
+        if (g_live_lines[i].ctx == ctx) { g_live_lines.erase(g_live_lines.begin() + (long)i); break; }
 }
 constexpr size_t BIG_BUFFER = (size_t)256 << 20;
 
@@ -347,7 +320,8 @@ struct arcte_hip_ctx {
     int64_t line_stats[4] = {0, 0, 0, 0};   // last run: LDS updates, blind line writes, read-modify-writes, updates of pushed nodes
     std::vector<double> placement_probe;    // G updates/s of every candidate allocation of the slot memory, in draw order
     int placement_kept = -1;
-    int registered = 0;                     // counted in g_live_lines_devices
+    int registered = 0;                     // listed in g_live_lines
+    int shared_device = 0;                  // another large line-state context of this process lives on the device
     DevBuf<double> dump_s, dump_r;          // arcte_hip_seed_state: the one seed's dense s and r (LineParams::dump_s)
     int dump_on = 0;
     // per-run
@@ -598,7 +572,7 @@ int draw_slot_memory(arcte_hip_ctx *c, size_t slots, size_t block)
     if (bytes < ((size_t)std::max(1, env_int("ARCTE_HIP_PLACEMENT_MIN_MB", 1024)) << 20) || slots < 256 ||
         c->n < (int64_t)env_int("ARCTE_HIP_PLACEMENT_MIN_NODES", 262144))
         tries = 1;
-    if (live_line_contexts_on(c->device) > (c->registered ? 1 : 0)) tries = 1;          // the device is shared: see g_live_lines_devices
+    if (c->shared_device) tries = 1;          // another large context of this process lives on the device: see g_live_lines
     if (tries == 1) {
         HIP_TRY(c->l_block.alloc(bytes, c->device));
         return 0;
@@ -1161,11 +1135,6 @@ int ensure_dense(arcte_hip_ctx *c, bool full)
 int setup_lines(arcte_hip_ctx *c, uint32_t M)
 {
     const int64_t n = c->n;
-    if (!c->registered) {
-        std::lock_guard<std::mutex> lock(g_big_mutex);
-        g_live_lines_devices.push_back(c->device);
-        c->registered = 1;
-    }
     c->l_M = M;
     c->l_Mshift = 0;
     while ((1u << c->l_Mshift) < M) c->l_Mshift++;
@@ -1220,11 +1189,16 @@ int setup_lines(arcte_hip_ctx *c, uint32_t M)
     // device has the room; the packed layout is what remains otherwise (several contexts on one GPU).  The levels exist
     // for spread slots too (another box: 23.8 / 23.9 / 20.0 in three processes), so the placement draw stays, over fewer
     // candidates.
+    // what this context is about to ask for, and whether it shares the device (decided once, before any allocation)
+    if (!c->registered) {
+        c->shared_device = plan_slot_memory(c->device, c, (size_t)slots * lines_bytes_per_slot(c, qcap, pcap, scap)) ? 1 : 0;
+        c->registered = 1;
+    }
     auto decide_spread = [&]() {
         c->l_spread = 0;
         const int spread_mb = env_int("ARCTE_HIP_SLOT_SPREAD_MB", 16);
         if (spread_mb <= 0 || slots < 256 || n < (int64_t)env_int("ARCTE_HIP_PLACEMENT_MIN_NODES", 262144)) return;
-        if (live_line_contexts_on(c->device) > (c->registered ? 1 : 0)) return;          // a shared device: packed slots
+        if (c->shared_device) return;          // packed slots
         c->l_spread = 1;                                          // (1: behind one another without padding)
         const size_t needed = lines_bytes_per_slot(c, qcap, pcap, scap);
         size_t stride = (size_t)spread_mb << 20;
@@ -1732,9 +1706,7 @@ int arcte_hip_destroy(arcte_hip_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->registered) {
-        std::lock_guard<std::mutex> lock(g_big_mutex);
-        for (size_t i = 0; i < g_live_lines_devices.size(); i++)
-            if (g_live_lines_devices[i] == c->device) { g_live_lines_devices.erase(g_live_lines_devices.begin() + (long)i); break; }
+        forget_slot_memory_plan(c);
         c->registered = 0;
     }
     c->indptr.release(); c->indices.release(); c->data.release(); c->out_degree.release(); c->in_degree.release();
