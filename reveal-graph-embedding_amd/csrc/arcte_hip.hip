@@ -149,6 +149,45 @@ void forget_slot_memory_plan(const void *ctx)
     for (size_t i = 0; i < g_live_lines.size(); i++)
         if (g_live_lines[i].ctx == ctx) { g_live_lines.erase(g_live_lines.begin() + (long)i); break; }
 }
+struct BestProbe { int device; size_t bytes; double rate; };
+std::vector<BestProbe> g_best_probe;
+
+bool free_parked_buffers()
+{
+    std::lock_guard<std::mutex> lock(g_big_mutex);
+    const bool any = !g_parked.empty();
+    int current = 0;
+    const bool have_current = hipGetDevice(&current) == hipSuccess;
+    for (auto &e : g_parked) {
+        (void)hipSetDevice(e.device);
+        (void)hipFree(e.p);
+    }
+    g_parked.clear();
+    if (any && have_current) (void)hipSetDevice(current);        // (the caller's allocation goes on)
+    return any;
+}
+
+// the parked buffers of one device: all of them, or (keep_bytes > 0) those of any other size -- a draw of another shape
+// has no use for them and they would sit on memory the new slots want
+void free_parked_on(int device, size_t keep_bytes = 0)
+{
+    std::lock_guard<std::mutex> lock(g_big_mutex);
+    for (size_t i = 0; i < g_parked.size();) {
+        if (g_parked[i].device == device && (keep_bytes == 0 || g_parked[i].bytes != keep_bytes)) {
+            (void)hipFree(g_parked[i].p);          // (callers have set the device)
+            g_parked.erase(g_parked.begin() + (long)i);
+        } else i++;
+    }
+}
+
+size_t parked_bytes_on(int device)
+{
+    std::lock_guard<std::mutex> lock(g_big_mutex);
+    size_t b = 0;
+    for (const auto &e : g_parked)
+        if (e.device == device) b += e.bytes;
+    return b;
+}
 constexpr size_t BIG_BUFFER = (size_t)256 << 20;
 
 template <typename T>
