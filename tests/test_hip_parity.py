@@ -220,8 +220,18 @@ def test_zero_weight_edge_is_reported_not_miscomputed():
         oracle.worker(w, od, idg, np.array([0]), 0.1, 1e-5)
 
 
-def test_config1_rmat_all_seeds_matches_reference_hash():
-    """All 63 070 seeds of the config-1 graph: SHA-256 of the canonical CSR against the reference's own run."""
+@pytest.mark.parametrize("state", ["default", "region B dense", "region B indirect", "packed words escape"])
+def test_config1_rmat_all_seeds_matches_reference_hash(state, monkeypatch):
+    """All 63 070 seeds of the config-1 graph: SHA-256 of the canonical CSR against the reference's own run -- with the
+    defaults (everything in region A), and with the LDS bitmap cut to 1 024 lines, so that 92 % of the nodes live in region B
+    (dense lines, then indirect ones: hub rows of 15 000 edges put several lanes of one 64-edge step into one line of region
+    B, the case the claims must order), and with packed row words that leave 3 bits for the in_degree."""
+    if state.startswith("region B"):
+        monkeypatch.setenv("ARCTE_HIP_LINES_LDS", "1024")
+        monkeypatch.setenv("ARCTE_HIP_HOT", "64")
+        monkeypatch.setenv("ARCTE_HIP_B_INDIRECT", "1" if state.endswith("indirect") else "0")
+    if state.startswith("packed"):
+        monkeypatch.setenv("ARCTE_HIP_PACK_RANK_BITS", "29")
     z = np.load(os.path.join(GOLDEN, "rmat100k_summary.npz"))
     adjacency = rmat_graph(100000, 2000000, seed=0)
     f = arcte(adjacency, float(z["rho"]), float(z["epsilon"]), 1)
