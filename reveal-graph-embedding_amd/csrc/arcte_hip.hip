@@ -652,7 +652,8 @@ int draw_slot_memory(arcte_hip_ctx *c, size_t slots, size_t block)
             const double alloc_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - ta).count();
             alloc_spent_s += alloc_s;
             if (env_int("ARCTE_HIP_VERBOSE", 0))
-                fprintf(stderr, "[arcte_hip] slot memory candidate %d: %.1f GB allocated in %.3f s\n", t, bytes / 1e9, alloc_s);
+                fprintf(stderr, "[arcte_hip] slot memory candidate %d: %.1f GB allocated in %.3f s at %p (address mod 64 MB: %llu MB)\n", t, bytes / 1e9, alloc_s,
+                        (void *)cand[(size_t)t].p, (unsigned long long)(((uintptr_t)cand[(size_t)t].p >> 20) & 63));
             // (on some boxes a large hipMalloc that follows frees takes seconds -- profiles/r03/first_call_1m.txt; the draw goes on
             //  all the same: ending it there left the first call of arcte() as slow as before -- the output buffers' allocations
             //  are as slow -- and the context without its protection against the slow level)
@@ -666,6 +667,7 @@ int draw_slot_memory(arcte_hip_ctx *c, size_t slots, size_t block)
             }
             const double rate = (double)slots * WAVE * 128 / (ms * 1e-3) / 1e9;
             c->placement_probe.push_back(rate);
+            if (env_int("ARCTE_HIP_VERBOSE", 0)) fprintf(stderr, "[arcte_hip] slot memory candidate %d probes at %.2f G updates/s\n", t, rate);
             if (best < 0 || rate > c->placement_probe[(size_t)best]) best = t;
             const double slowest = *std::min_element(c->placement_probe.begin(), c->placement_probe.end());
             // (packed slots: two classes, 20 and 24 -- a fast one in hand is enough; spread slots have a top level at 26 that a
@@ -673,15 +675,13 @@ int draw_slot_memory(arcte_hip_ctx *c, size_t slots, size_t block)
             if (!c->l_spread && c->placement_probe[(size_t)best] >= 1.1 * slowest) break;
             // Spread slots: the probe's levels are 20, 22, 24 and 26 G updates/s on every box so far (the push kernel: ~750, 680, 630 and
             // 590 ms per launch of the 1M/50M graph).  A candidate on the top level ends the draw at once (one allocation, nothing
-            // parked).  Below it the draw goes on to a THIRD candidate -- of the round-4 draws that took three, the third sat on the top
-            // level in eleven of twenty-one (a later allocation lands there more often than the first) -- at the price of a third
-            // hipMalloc of 51.5 GB, which took 2.7 s on two boxes; from the third candidate on the 24 level is good enough, and only a
-            // draw that holds nothing but the slow level goes on to ARCTE_HIP_SPREAD_TRIES (4) candidates: two slow candidates in a row
-            // happened in one of eleven round-4 processes (0.296 instead of 0.35-0.38).
-            if (c->l_spread) {
-                if (c->placement_probe[(size_t)best] >= level_good) break;
-                if (t >= 2 && c->placement_probe[(size_t)best] >= level_ok) break;
-            }
+            // parked).  Below it the draw goes on, to ARCTE_HIP_SPREAD_TRIES (4) candidates: WHERE an allocation lands decides its
+            // level, and later ones land better -- six processes with four forced candidates each on one box
+            // (profiles/r04/draw_by_position.txt): the first candidate on the slow level six times of six, the best of three
+            // 25.7 / 23.9 / 25.3 / 24.2 / 24.0 / 24.2, the best of four 25.7 / 23.9 / 25.3 / 25.7 / 25.2 / 25.3.  The price is hipMalloc
+            // time on boxes where one allocation in three or four takes seconds: past ARCTE_HIP_DRAW_ALLOC_MS a draw that holds a
+            // candidate off the slow level stops (the check above).
+            if (c->l_spread && c->placement_probe[(size_t)best] >= level_good) break;
             if (known_best > 0.0 && c->placement_probe[(size_t)best] >= 0.97 * known_best) break;   // as good as this process has seen
         }
         if (best < 0) return fail(ARCTE_HIP_EHIP, "no memory for the propagation slots");
