@@ -618,9 +618,11 @@ int draw_slot_memory(arcte_hip_ctx *c, size_t slots, size_t block)
     }
     if (c->l_spread) tries = std::min(tries, std::max(1, env_int("ARCTE_HIP_SPREAD_TRIES", 4)));      // (candidates of 50 GB and more)
     free_parked_on(c->device, bytes);          // losers of a draw of another shape: of no use to this one
-    // A draw may cost this much allocation time before it settles for what it holds (on some boxes a hipMalloc of tens of
-    // GB takes a second or more, profiles/r03/first_call_1m.txt: there the third candidate is not worth its price)
-    const double alloc_budget_s = std::max(0, env_int("ARCTE_HIP_DRAW_ALLOC_MS", 400)) * 1e-3;
+    // A draw may cost this much allocation time before it settles for a candidate off the slow level (on some boxes one hipMalloc
+    // of tens of GB in three or four takes 1.5-3.7 s, profiles/r04/draw_by_position.txt).  3 s: a process that runs graphs of this
+    // size spends longer reading them, and a level is worth 6 % of every run that follows; 400 ms let one bench run settle for a
+    // single candidate at 23.5 (0.352).
+    const double alloc_budget_s = std::max(0, env_int("ARCTE_HIP_DRAW_ALLOC_MS", 3000)) * 1e-3;
     const double level_good = 0.1 * std::max(1, env_int("ARCTE_HIP_DRAW_GOOD_X10", 250)), level_ok = 0.1 * std::max(1, env_int("ARCTE_HIP_DRAW_OK_X10", 230));
     double alloc_spent_s = 0.0;
     std::vector<SlotMem> cand((size_t)tries);
