@@ -645,6 +645,8 @@ int draw_slot_memory(arcte_hip_ctx *c, size_t slots, size_t block)
                 size_t free_b = 0, total_b = 0;
                 HIP_TRY(hipMemGetInfo(&free_b, &total_b));
                 if (free_b + cached_bytes_on(c->device) < bytes + bytes / 2 + ((size_t)24 << 30)) break;      // no room for another candidate
+                // (nor one that would leave the device past 65 % full with its loser parked: the edge of profiles/r03/device_fill_8m.txt)
+                if (t >= 2 && total_b - std::min(total_b, free_b) + bytes > total_b / 100 * 80) break;
                 // (the allocation-time budget ends a draw that holds a candidate off the slow level; a draw that holds only slow
                 //  ones goes on -- 750 against 590-630 ms per launch is worth seconds of hipMalloc)
                 if (alloc_spent_s > alloc_budget_s && best >= 0 && c->placement_probe[(size_t)best] >= level_ok) break;
@@ -821,6 +823,7 @@ int launch_lines_v(arcte_hip_ctx *c, const PushParams &P, const LineParams &L, i
     // rows: 0 wide, 1 narrow (rank + float32 in_degree), 2 packed (one word per edge; c->edge_rank holds the packed words then)
     const int rows = c->pack ? 2 : (c->narrow ? 1 : 0);
     if (tail && c->l_ind) {         // region B's lines indirect
+        if (rows == 2 && MODE == 0 && VAR == 0 && c->l_waves_per_cu > 12) return go(k_arcte_lines<0, 0, 2, true, false, 1, 4, false, true>);
         if (rows == 2) return go(k_arcte_lines<MODE, VAR, 2, true, false, 1, 1, false, true>);
         return rows == 1 ? go(k_arcte_lines<MODE, VAR, 1, true, false, 1, 1, false, true>) : go(k_arcte_lines<MODE, VAR, 0, true, false, 1, 1, false, true>);
     }
@@ -834,6 +837,13 @@ int launch_lines_v(arcte_hip_ctx *c, const PushParams &P, const LineParams &L, i
     if (rows == 1 && MODE == 0 && VAR == 0 && c->l_waves_per_cu > 12)      // four wavefronts per SIMD: the compiler spills to fit 128 VGPRs
         return tail ? go(k_arcte_lines<0, 0, 1, true, false, 1, 4>) : go(k_arcte_lines<0, 0, 1, false, false, 1, 4>);
 #endif
+    // more than twelve wavefronts per CU (ARCTE_HIP_WAVES_PER_CU; ARCTE's worker on packed rows): the build that fits four
+    // wavefronts per SIMD (128 VGPRs, the compiler spills the rest).  An experiment knob: large graphs, whose rows are short, are
+    // sensitive to the wavefronts in flight (8M-node graph: 0.184 / 0.222 at 9 / 12 per CU, profiles/r04/large_graph_sweep.txt)
+    if (rows == 2 && MODE == 0 && VAR == 0 && c->l_waves_per_cu > 12) {
+        if (tail && c->l_ind) return go(k_arcte_lines<0, 0, 2, true, false, 1, 4, false, true>);
+        return tail ? go(k_arcte_lines<0, 0, 2, true, false, 1, 4>) : go(k_arcte_lines<0, 0, 2, false, false, 1, 4>);
+    }
     if (rows == 2) return tail ? go(k_arcte_lines<MODE, VAR, 2, true, false, 1>) : go(k_arcte_lines<MODE, VAR, 2, false, false, 1>);
     if (rows == 1) return tail ? go(k_arcte_lines<MODE, VAR, 1, true, false, 1>) : go(k_arcte_lines<MODE, VAR, 1, false, false, 1>);
     return tail ? go(k_arcte_lines<MODE, VAR, 0, true, false, 1>) : go(k_arcte_lines<MODE, VAR, 0, false, false, 1>);
@@ -888,7 +898,10 @@ int launch_lines(arcte_hip_ctx *c, PushParams P, int64_t nwork, int variant, int
     P.queue = reinterpret_cast<QEntry *>(c->l_block.p + c->l_off_queue);
     P.qcap = c->l_qcap;
     const size_t lds = (size_t)L.K * sizeof(double) + c->l_M / 8 + (stage_rows_on() ? 2560 : 0);
-    const int blocks = (int)std::min<int64_t>(c->l_slots, std::max<int64_t>(nwork, 1));
+    int blocks = (int)std::min<int64_t>(c->l_slots, std::max<int64_t>(nwork, 1));
+    // (only ARCTE's worker on packed rows has the build that fits more than twelve wavefronts per CU; the others run on the first
+    //  twelve slots per CU of a context that has more)
+    if (c->l_waves_per_cu > 12 && !(c->pack && mode == 0 && variant == 0)) blocks = std::min<int>(blocks, 12 * c->cus);
     if (mode == 2) return launch_lines_v<2, 0>(c, P, L, blocks, lds);
 #ifdef ARCTE_HIP_AB_BUILDS          // ARCTE_HIP_PROFILE=1: the instrumented instantiation (tools/phase_profile.py)
     if (c->prof.p && c->narrow && variant == 0 && !c->l_ind) {
@@ -1208,7 +1221,18 @@ int setup_lines(arcte_hip_ctx *c, uint32_t M)
     int64_t slots = c->want_slots;
     const bool auto_slots = slots <= 0;
     if (auto_slots) {
-        c->l_waves_per_cu = std::max(1, std::min(env_int("ARCTE_HIP_WAVES_PER_CU", 12), 32));
+        // Wavefronts per CU.  Twelve is what the 156-VGPR kernel admits (three per SIMD).  ARCTE's worker on packed rows also exists
+        // as a 128-VGPR build (four per SIMD; the compiler spills 76-144 bytes per lane), and on graphs whose rows are short the
+        // wavefronts in flight are worth more than the registers (profiles/r04/occupancy_sweeps.txt, frac of 8 TB/s):
+        //   1M/50M   12: 0.365-0.382   14: 0.375-0.386 (-2 % time at equal memory level)   16: 0.373 / 0.357 (8 / 4 KB of touched-bits)
+        //   4M/100M  12: 0.285         14: 0.304                                           16: 0.317 / 0.301-0.305
+        //   8M/100M  12: 0.226         14: 0.245                                           16: 0.245 / 0.257-0.260
+        //   16M/200M 12: 0.229         14: 0.155                                           16: 0.172 / 0.165
+        // So: fourteen while region B is dense (n < ~2.5 M), sixteen with indirect region B up to 12 M nodes, twelve beyond
+        // (and for every graph without packed rows: the other instantiations need their 140-190 VGPRs).
+        int waves_default = 12;
+        if (c->pack) waves_default = !c->l_ind ? 14 : (n < 12000000 ? 16 : 12);
+        c->l_waves_per_cu = std::max(1, std::min(env_int("ARCTE_HIP_WAVES_PER_CU", waves_default), 32));
         slots = (int64_t)c->l_waves_per_cu * c->cus;
     }
     size_t free_b = 0, total_b = 0;
@@ -1410,7 +1434,10 @@ int ctx_finish(arcte_hip_ctx *c, int64_t n_slots, int64_t queue_capacity)
     //      each) a bitmap of 8 KB + 512 on-chip values beats 4 KB + 1 024 and 2 KB + 1 280 (ms per 81 434 seeds, interleaved
     //      processes on one box: 78.2 / 83.0 / 85.6; 4M-node graph 282 / 290), and 16 KB leaves no wavefront its share
     const char *state_env = getenv("ARCTE_HIP_STATE");
-    const uint32_t lines_lds = next_pow2((uint64_t)std::max(64, env_int("ARCTE_HIP_LINES_LDS", 65536)));
+    //      Round 4 (profiles/r04/occupancy_sweeps.txt): on graphs of 6-12 M nodes (sparser rows, region B's lines indirect, sixteen
+    //      wavefronts per CU: setup_lines) 4 KB of touched-bits + 640 on-chip values beat 8 KB + 128: 0.257-0.260 against 0.245 at 8M.
+    const int lines_default = (c->pack && n >= 6000000 && n < 12000000) ? 32768 : 65536;
+    const uint32_t lines_lds = next_pow2((uint64_t)std::max(64, env_int("ARCTE_HIP_LINES_LDS", lines_default)));
     const uint32_t M = std::min<uint32_t>(lines_lds, std::max<uint32_t>(64u, next_pow2((uint64_t)((n + 7) / 8))));
     c->lines = !(state_env && state_env[0] == 'd') && !c->coop;
     int r = c->lines ? setup_lines(c, M) : setup_dense(c, n_slots, queue_capacity);
@@ -3268,6 +3295,14 @@ int arcte_hip_launch_occupancy(arcte_hip_ctx *c, int *workgroups_per_cu)
     if (c->lines && !c->float32) {
         const size_t lds = (size_t)lines_hot_values(c) * sizeof(double) + c->l_M / 8;
         int per_cu = 0;
+        if (c->pack && c->l_waves_per_cu > 12) {
+            auto k4 = (c->l_MB > 0 && c->l_ind) ? k_arcte_lines<0, 0, 2, true, false, 1, 4, false, true>
+                                                : (c->l_MB > 0 ? k_arcte_lines<0, 0, 2, true, false, 1, 4> : k_arcte_lines<0, 0, 2, false, false, 1, 4>);
+            if (lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k4), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k4, WAVE, lds));
+            *workgroups_per_cu = per_cu;
+            return 0;
+        }
         auto kernel = c->pack ? (c->l_MB > 0 ? k_arcte_lines<0, 0, 2, true, false, 1> : k_arcte_lines<0, 0, 2, false, false, 1>)
                       : c->narrow ? (c->l_MB > 0 ? k_arcte_lines<0, 0, 1, true, false, 1> : k_arcte_lines<0, 0, 1, false, false, 1>)
                                   : (c->l_MB > 0 ? k_arcte_lines<0, 0, 0, true, false, 1> : k_arcte_lines<0, 0, 0, false, false, 1>);
