@@ -707,7 +707,12 @@ int draw_slot_memory(arcte_hip_ctx *c, size_t slots, size_t block)
         // that memory out again and one deferred hipFree less is paid for by the next hipMalloc -- the others go back to the
         // driver before the context exists (round 3 kept them all: 155 GB held for a 1M-node graph).  The best rate is
         // remembered for the next context of this shape.
-        const int park_max = std::max(0, env_int("ARCTE_HIP_PARK_MAX", 1));
+        // ... and none when the kept buffer and a parked one together would hold more than 35 % of the device: the 14 / 16
+        // wavefronts per CU of round 4 make candidates of 60-69 GB, and two of those beside the output buffers of a whole launch
+        // of the 8M-node graph put the device past its fill edge (5 611 against ~3 700 ms per launch, profiles/r04/occupancy_sweeps.txt)
+        size_t total_dev = 0, free_dev = 0;
+        (void)hipMemGetInfo(&free_dev, &total_dev);
+        const int park_max = (total_dev && 2 * bytes > total_dev / 100 * 35) ? 0 : std::max(0, env_int("ARCTE_HIP_PARK_MAX", 1));
         std::vector<std::pair<double, size_t>> losers;          // (probe rate, candidate)
         for (size_t i = 0; i < cand.size(); i++)
             if (cand[i].plain.p) losers.push_back({i < c->placement_probe.size() ? c->placement_probe[i] : 0.0, i});
@@ -1970,7 +1975,7 @@ static int run_seeds_impl(arcte_hip_ctx *c, const int64_t *seeds, int64_t nseeds
         HIP_TRY(hipMemGetInfo(&free_b, &total_b));
         // 4096 rows per seed is ~3x what power-law graphs emit on average; the arena is reused by later
         // runs and re-filled (failed seeds re-run) when it is still too small
-        size_t want = std::max<size_t>((size_t)c->n, std::min<size_t>((size_t)nseeds * 4096, (size_t)1 << 32));
+        size_t want = std::max<size_t>((size_t)c->n, std::min<size_t>((size_t)nseeds * 4096, (size_t)1 << 33));       // (3.1 M seeds of the 8M graph emit 5.9 G rows)
         want = std::min(want, std::max<size_t>((size_t)c->n, free_b / 4 / sizeof(int32_t)));
         if (const char *env = getenv("ARCTE_HIP_ARENA_ROWS")) {   // test hook: force a small arena
             long long v = atoll(env);
