@@ -1233,10 +1233,14 @@ int setup_lines(arcte_hip_ctx *c, uint32_t M)
         //   4M/100M  12: 0.285         14: 0.304                                           16: 0.317 / 0.301-0.305
         //   8M/100M  12: 0.226         14: 0.245                                           16: 0.245 / 0.257-0.260
         //   16M/200M 12: 0.229         14: 0.155                                           16: 0.172 / 0.165
-        // So: fourteen while region B is dense (n < ~2.5 M), sixteen with indirect region B up to 12 M nodes, twelve beyond
-        // (and for every graph without packed rows: the other instantiations need their 140-190 VGPRs).
+        // (8M and 16M: launches of a quarter / a sixteenth of the seeds.)  A WHOLE launch of the 8M graph does not keep that gain: its
+        // heaviest seeds make more claims of region B than a pool of 131 072 lines holds (every claim takes a pool line, arcte_lines.hpp),
+        // the pools grow to 524 288 lines = 32 MB per slot, 4 096 such slots no longer fit the memory rule of grow_lines and the context
+        // falls back to 2 048 slots: 5 665 ms per launch (0.170) against 4 230 (0.228) with twelve per CU (tools/whole_launch_probe.py).
+        // So: fourteen while region B is dense (n < ~2.5 M), sixteen with indirect region B below 6 M nodes, twelve beyond (and for
+        // every graph without packed rows: the other instantiations need their 140-190 VGPRs).  Next: pools sized per seed class.
         int waves_default = 12;
-        if (c->pack) waves_default = !c->l_ind ? 14 : (n < 12000000 ? 16 : 12);
+        if (c->pack) waves_default = !c->l_ind ? 14 : (n < 6000000 ? 16 : 12);
         c->l_waves_per_cu = std::max(1, std::min(env_int("ARCTE_HIP_WAVES_PER_CU", waves_default), 32));
         slots = (int64_t)c->l_waves_per_cu * c->cus;
     }
