@@ -795,7 +795,8 @@ int grow_lines(arcte_hip_ctx *c, bool queue_over, bool pushed_over, bool sup_ove
         // (ARCTE_HIP_B_INDIRECT=1: the pool keeps growing, to 2^26 lines), slots whose pool passes TWICE the dense lines get dense
         // lines, which cannot overflow.
         if (c->l_pool >= (1u << 26)) return fail(ARCTE_HIP_ECAPACITY, "region B's pool cannot grow past 2^26 lines");
-        c->l_pool *= 4;
+        // (four times while a pool is small, twice from 8 MB on: every slot pays for what the heaviest seed of the graph needs)
+        c->l_pool *= c->l_pool >= (1u << 17) ? 2 : 4;
         if (c->l_pool > 2 * (uint64_t)c->l_MB && env_int("ARCTE_HIP_B_INDIRECT", -1) != 1) { c->l_ind = 0; c->l_gen.release(); }
     }
     // (the slot memory changes its shape: losers of the old shape's draw are of no use any more, and left allocated they
@@ -804,8 +805,13 @@ int grow_lines(arcte_hip_ctx *c, bool queue_over, bool pushed_over, bool sup_ove
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
     free_b += c->slot_bytes_lines() + cached_bytes_on(c->device);
+    // (fewer slots by half a wavefront per CU at a time, as setup_lines does; round 4's first version halved them and a whole launch
+    //  of the 8M-node graph went from 4 096 slots to 2 048 for 2 % of memory: tools/whole_launch_probe.py)
     int64_t slots = c->l_slots;
-    while (slots > 1 && (size_t)slots * lines_bytes_per_slot(c, qcap, pcap, scap) > free_b / 4 * 3) slots = (slots + 1) / 2;
+    const size_t per_slot = lines_bytes_per_slot(c, qcap, pcap, scap);
+    while (slots > c->cus && (size_t)slots * per_slot > free_b / 4 * 3) slots -= std::max(1, c->cus / 2);
+    while (slots > 1 && (size_t)slots * per_slot > free_b / 4 * 3) slots = (slots + 1) / 2;
+    c->l_waves_per_cu = (int)std::max<int64_t>(1, std::min<int64_t>(32, (slots + c->cus - 1) / c->cus));
     c->l_block.release(c->device);
     c->l_blockb.release(c->device);
     return alloc_lines(c, slots, qcap, pcap, scap);
@@ -1232,15 +1238,16 @@ int setup_lines(arcte_hip_ctx *c, uint32_t M)
         //   1M/50M   12: 0.365-0.382   14: 0.375-0.386 (-2 % time at equal memory level)   16: 0.373 / 0.357 (8 / 4 KB of touched-bits)
         //   4M/100M  12: 0.285         14: 0.304                                           16: 0.317 / 0.301-0.305
         //   8M/100M  12: 0.226         14: 0.245                                           16: 0.245 / 0.257-0.260
-        //   16M/200M 12: 0.229         14: 0.155                                           16: 0.172 / 0.165
-        // (8M and 16M: launches of a quarter / a sixteenth of the seeds.)  A WHOLE launch of the 8M graph does not keep that gain: its
-        // heaviest seeds make more claims of region B than a pool of 131 072 lines holds (every claim takes a pool line, arcte_lines.hpp),
-        // the pools grow to 524 288 lines = 32 MB per slot, 4 096 such slots no longer fit the memory rule of grow_lines and the context
-        // falls back to 2 048 slots: 5 665 ms per launch (0.170) against 4 230 (0.228) with twelve per CU (tools/whole_launch_probe.py).
-        // So: fourteen while region B is dense (n < ~2.5 M), sixteen with indirect region B below 6 M nodes, twelve beyond (and for
-        // every graph without packed rows: the other instantiations need their 140-190 VGPRs).  Next: pools sized per seed class.
+        //   16M/200M 12: 0.227         14: 0.242                                           16: - / 0.243
+        // (8M and 16M: launches of a quarter / a sixteenth of the seeds.)  A WHOLE launch of the 8M graph makes the pools of region B
+        // grow to what its heaviest seeds claim (262 144 lines = 16 MB per slot; 56 502 of the 3 142 632 seeds outgrow the first
+        // 32 768), and keeps the gain as long as grow_lines keeps the slots: 3 730-3 809 ms per launch (0.259-0.253) with sixteen per
+        // CU against 4 230-4 530 (0.228-0.213) with twelve, one context each (tools/whole_launch_probe.py).  (The first sweeps of the
+        // 16M graph said 0.155-0.172 for 14 / 16: grow_lines HALVED the slots then, once a pool had grown.)
+        // So: fourteen while region B is dense (n < ~2.5 M), sixteen with indirect region B -- fewer when the memory says so, below --
+        // and twelve for every graph without packed rows: the other instantiations need their 140-190 VGPRs.
         int waves_default = 12;
-        if (c->pack) waves_default = !c->l_ind ? 14 : (n < 6000000 ? 16 : 12);
+        if (c->pack) waves_default = !c->l_ind ? 14 : 16;
         c->l_waves_per_cu = std::max(1, std::min(env_int("ARCTE_HIP_WAVES_PER_CU", waves_default), 32));
         slots = (int64_t)c->l_waves_per_cu * c->cus;
     }
@@ -1443,9 +1450,10 @@ int ctx_finish(arcte_hip_ctx *c, int64_t n_slots, int64_t queue_capacity)
     //      each) a bitmap of 8 KB + 512 on-chip values beats 4 KB + 1 024 and 2 KB + 1 280 (ms per 81 434 seeds, interleaved
     //      processes on one box: 78.2 / 83.0 / 85.6; 4M-node graph 282 / 290), and 16 KB leaves no wavefront its share
     const char *state_env = getenv("ARCTE_HIP_STATE");
-    //      Round 4 (profiles/r04/occupancy_sweeps.txt): on graphs of 6-12 M nodes (sparser rows, region B's lines indirect, sixteen
-    //      wavefronts per CU: setup_lines) 4 KB of touched-bits + 640 on-chip values beat 8 KB + 128: 0.257-0.260 against 0.245 at 8M.
-    const int lines_default = (c->pack && n >= 6000000 && n < 12000000) ? 32768 : 65536;
+    //      Round 4 (profiles/r04/occupancy_sweeps.txt): on graphs of 6 M nodes and more (sparser rows, region B's lines indirect,
+    //      sixteen wavefronts per CU: setup_lines) 4 KB of touched-bits + 640 on-chip values beat 8 KB + 128: 0.257-0.260 against
+    //      0.245 at 8M (16M: 0.243 with 4 KB); at 4M 8 KB still wins (0.317 against 0.301-0.305).
+    const int lines_default = (c->pack && n >= 6000000) ? 32768 : 65536;
     const uint32_t lines_lds = next_pow2((uint64_t)std::max(64, env_int("ARCTE_HIP_LINES_LDS", lines_default)));
     const uint32_t M = std::min<uint32_t>(lines_lds, std::max<uint32_t>(64u, next_pow2((uint64_t)((n + 7) / 8))));
     c->lines = !(state_env && state_env[0] == 'd') && !c->coop;
