@@ -2476,6 +2476,9 @@ static int assemble_csr_device(arcte_hip_ctx *c, int with_base_block, DevBuf<int
         local_cols = next_col;
     }
     if (n_local_cols) *n_local_cols = local_cols;
+    const bool verbose = env_int("ARCTE_HIP_VERBOSE", 0) != 0;
+    const auto t_start = std::chrono::steady_clock::now();
+    auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count(); };
     int rc = [&]() -> int {
         if (c->centrality_run) {
             HIP_TRY(colid_d.alloc(ns));
@@ -2489,6 +2492,7 @@ static int assemble_csr_device(arcte_hip_ctx *c, int with_base_block, DevBuf<int
         HIP_TRY(colptr_d.alloc(ns + 1));
         HIP_TRY(dst_d.alloc(ns));
         HIP_TRY(seg_d.alloc(ns));
+        const double t_alloc = since();
         HIP_TRY(hipMemcpyAsync(colptr_d.p, c->colptr.data(), (ns + 1) * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
         if (ns) {
             HIP_TRY(hipMemcpyAsync(dst_d.p, dst.data(), ns * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
@@ -2518,9 +2522,14 @@ static int assemble_csr_device(arcte_hip_ctx *c, int with_base_block, DevBuf<int
         HIP_TRY(hipMemcpyAsync(&valid, indptr_d.p + n, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
         *valid_out = valid;
+        if (verbose)
+            fprintf(stderr, "[arcte_hip] CSR assembly of %lld pairs: %.1f ms to the buffers (host order of the seeds + device allocations), %.1f ms pairs + sort + indptr\n",
+                    (long long)nkeys, t_alloc, since() - t_alloc);
         return 0;
     }();
+    const double t_done = since();
     key_a.release(); key_b.release(); val_a.release(); colptr_d.release(); dst_d.release(); seg_d.release(); colid_d.release(); temp.release();
+    if (verbose) fprintf(stderr, "[arcte_hip] CSR assembly: %.1f ms to give the sort's buffers back\n", since() - t_done);
     return rc;
 }
 
@@ -2535,9 +2544,15 @@ int arcte_hip_fetch_result_csr(arcte_hip_ctx *c, int with_base_block, int64_t *i
         if (valid && !indices) return fail(ARCTE_HIP_EINVAL, "indices is NULL");
         HIP_TRY(hipMemcpy(indptr, indptr_d.p, (c->n + 1) * sizeof(int64_t), hipMemcpyDeviceToHost));
         // the column ids go out in pieces, so that the pageable destination is faulted in while the next piece moves
+        // (Round 4: a destination pinned by hipHostRegister, taken in one piece, gains nothing -- 881 M column ids in 115.7 ms either
+        //  way on a box whose link moves 30.5 GB/s, whichever NUMA node touched the pages first: profiles/r04/e2e_arcte_1m.txt)
         const int64_t piece = (int64_t)64 << 20;
+        const auto t0 = std::chrono::steady_clock::now();
         for (int64_t o = 0; o < valid; o += piece)
             HIP_TRY(hipMemcpy(indices + o, cols.p + o, std::min(piece, valid - o) * sizeof(int32_t), hipMemcpyDeviceToHost));
+        if (env_int("ARCTE_HIP_VERBOSE", 0))
+            fprintf(stderr, "[arcte_hip] CSR copy-out of %lld column ids: %.1f ms\n", (long long)valid,
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
         *nnz_out = valid;
         return 0;
     }();
