@@ -5,6 +5,7 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r04
 mkdir -p $O
 cd $R
+python bench.py > $O/bench_default.json 2> $O/bench_default.log; echo "bench default $?"
 python bench.py --variant pagerank --steps 3 --cpu-seconds 0 > $O/bench_variant_pagerank.json 2>/dev/null; echo "pagerank $?"
 python bench.py --variant lazy --steps 3 --cpu-seconds 0 > $O/bench_variant_lazy_pagerank.json 2>/dev/null; echo "lazy $?"
 python bench.py --nodes 4000000 --edges 100000000 --steps 2 --cpu-seconds 0 > $O/bench_n4M_m100M.json 2>/dev/null; echo "4M $?"
