@@ -412,9 +412,11 @@ def main():
             "roofline": {
                 "bound": "hbm",
                 # (the name rocprofv3 prints: MODE, VAR, ROWS (0 wide, 1 narrow, 2 packed), TAIL, PROF, LT, WPE, STAGE, IND)
-                "kernel": ("void (anonymous namespace)::k_arcte_lines<0, %d, %d, %s, false, 1, 1, false, %s>((anonymous namespace)::PushParams, "
+                #  WPE = 4: the 128-VGPR build of ARCTE's worker on packed rows, launched with more than twelve wavefronts per CU)
+                "kernel": ("void (anonymous namespace)::k_arcte_lines<0, %d, %d, %s, false, 1, %d, false, %s>((anonymous namespace)::PushParams, "
                            "(anonymous namespace)::LineParams)" % (variant, info["narrow_rows"],
                                                                    "true" if state["lines_region_b"] else "false",
+                                                                   4 if (info["waves_per_cu"] > 12 and info["narrow_rows"] == 2 and variant == 0) else 1,
                                                                    "true" if state["region_b_indirect"] else "false")) if state["line_state"] else
                           "k_arcte_seeds<0, %d, %s, %d, %s%s>" % (variant, "float" if args.float32 else "double", info["tiles"],
                                                                   "true" if info["hot_values_per_wave"] else "false",

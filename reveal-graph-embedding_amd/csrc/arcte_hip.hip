@@ -2484,10 +2484,15 @@ static int assemble_csr_device(arcte_hip_ctx *c, int with_base_block, DevBuf<int
             HIP_TRY(colid_d.alloc(ns));
             if (ns) HIP_TRY(hipMemcpyAsync(colid_d.p, colid_h.data(), ns * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
         }
-        HIP_TRY(key_a.alloc(nkeys));
-        HIP_TRY(key_b.alloc(nkeys));
-        HIP_TRY(val_a.alloc(nkeys));
-        HIP_TRY(cols.alloc(nkeys));
+        // The sort's large buffers come from (and go back to) the process-wide cache: a second arcte() call of the same shape
+        // allocates nothing large.  That matters beyond the allocation's own time: memory given back to the driver -- the losers of
+        // the slot-memory draw, 60 GB each -- is cleared before it is handed out again, and the next LARGE hipMalloc waits for that
+        // (3 x 60 GB freed: 5.1 s; tools/free_cost_probe.hip, profiles/r04/free_cost_probe.txt).  It was these allocations that
+        // waited, in the first or the second call (profiles/r04/first_call_1m.txt).
+        HIP_TRY(alloc_cached(key_a, (size_t)nkeys, c->device));
+        HIP_TRY(alloc_cached(key_b, (size_t)nkeys, c->device));
+        HIP_TRY(alloc_cached(val_a, (size_t)nkeys, c->device));
+        HIP_TRY(alloc_cached(cols, (size_t)nkeys, c->device));
         HIP_TRY(indptr_d.alloc(n + 1));
         HIP_TRY(colptr_d.alloc(ns + 1));
         HIP_TRY(dst_d.alloc(ns));
@@ -2513,7 +2518,7 @@ static int assemble_csr_device(arcte_hip_ctx *c, int with_base_block, DevBuf<int
         while (end_bit < 32 && ((uint64_t)1 << end_bit) <= (uint64_t)n) end_bit++;
         size_t temp_bytes = 0;
         HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, key_a.p, key_b.p, val_a.p, cols.p, (size_t)nkeys, 0, end_bit, c->stream));
-        HIP_TRY(temp.alloc(temp_bytes));
+        HIP_TRY(alloc_cached(temp, temp_bytes, c->device));
         if (nkeys) HIP_TRY(hipcub::DeviceRadixSort::SortPairs(temp.p, temp_bytes, key_a.p, key_b.p, val_a.p, cols.p, (size_t)nkeys, 0, end_bit, c->stream));
         const int tb = 256;
         hipLaunchKernelGGL(k_rows_to_indptr_u32, dim3((unsigned)((n + 1 + tb - 1) / tb)), dim3(tb), 0, c->stream, key_b.p, nkeys, n, indptr_d.p);
@@ -2528,7 +2533,9 @@ static int assemble_csr_device(arcte_hip_ctx *c, int with_base_block, DevBuf<int
         return 0;
     }();
     const double t_done = since();
-    key_a.release(); key_b.release(); val_a.release(); colptr_d.release(); dst_d.release(); seg_d.release(); colid_d.release(); temp.release();
+    release_cached(key_a, c->device); release_cached(key_b, c->device); release_cached(val_a, c->device); release_cached(temp, c->device);
+    colptr_d.release(); dst_d.release(); seg_d.release(); colid_d.release();
+    if (rc) release_cached(cols, c->device);
     if (verbose) fprintf(stderr, "[arcte_hip] CSR assembly: %.1f ms to give the sort's buffers back\n", since() - t_done);
     return rc;
 }
@@ -2556,7 +2563,7 @@ int arcte_hip_fetch_result_csr(arcte_hip_ctx *c, int with_base_block, int64_t *i
         *nnz_out = valid;
         return 0;
     }();
-    indptr_d.release(); cols.release();
+    indptr_d.release(); release_cached(cols, c->device);
     return rc;
 }
 
@@ -3000,7 +3007,7 @@ int arcte_hip_features_from_result(arcte_hip_ctx *c, int with_base_block, arcte_
     int64_t valid = 0;
     int64_t local_cols = 0;
     int rc = assemble_csr_device(c, with_base_block, indptr_d, cols, &valid, &local_cols);
-    if (rc) { indptr_d.release(); cols.release(); return rc; }
+    if (rc) { indptr_d.release(); release_cached(cols, c->device); return rc; }
     arcte_hip_features *f = new arcte_hip_features();
     f->device = c->device; f->n_rows = c->n; f->n_cols = (with_base_block ? c->n : 0) + local_cols; f->nnz = valid;
     f->indptr = indptr_d; indptr_d.p = nullptr;
