@@ -153,6 +153,11 @@ def main():
     if args.backend == "nccl" and local_rank >= ndev:
         raise SystemExit("rank %d has no GPU of its own (%d visible): RCCL needs one GPU per rank" % (rank, ndev))
     gpu = local_rank % ndev
+    if world > ndev:
+        # The one-GPU rehearsal of the multi-rank path (--backend gloo): ranks SHARE a GPU.  The library's placement draw holds up to
+        # four candidate allocations of the slot memory at once (4 x 60 GB on the 1M/50M graph); another PROCESS setting up meanwhile
+        # sees a full device and sizes itself to one wavefront per CU (profiles/r04: 2 059 ms per launch).  One candidate per rank here.
+        os.environ.setdefault("ARCTE_HIP_SPREAD_TRIES", "1")
     torch.cuda.set_device(gpu)
     dev = torch.device("cuda", gpu)
     comm_dev = dev if args.backend == "nccl" else torch.device("cpu")
