@@ -49,8 +49,9 @@ int arcte_hip_device_count(int *count);
  * (eps_randomwalk/transition.py:43-99) and what arcte_worker receives
  * (embedding/arcte/arcte.py:279-286): CSR (indptr[n+1], indices[nnz] ascending inside a
  * row, data[nnz]) of W = D_out^-1 A, weighted out_degree[n], in_degree[n].
- * A slot is the scratch of one wavefront (one seed in flight): n_slots = 0 picks 12 wavefronts per compute unit
- * (ARCTE_HIP_WAVES_PER_CU overrides) of the LINE state (arcte_hip_state_info: 8 bytes per node and slot in strided
+ * A slot is the scratch of one wavefront (one seed in flight): n_slots = 0 picks 12 wavefronts per compute unit -- 14 on graphs
+ * whose rows pack into one 32-bit word per edge, 16 of those when region B's lines are indirect (n > ~2.5 M);
+ * ARCTE_HIP_WAVES_PER_CU overrides -- of the LINE state (arcte_hip_state_info: 8 bytes per node and slot in strided
  * 64-byte lines, a touched-line bitmap + the hottest nodes' values in LDS), fewer when the slot memory would take the
  * device past 65 % full; ARCTE_HIP_STATE=dense selects the round-2 state (32-byte entries, 6 wavefronts per CU);
  * the CU's LDS is divided among its resident wavefronts for the hot table.  queue_capacity = 0 picks
