@@ -805,6 +805,7 @@ int grow_lines(arcte_hip_ctx *c, bool queue_over, bool pushed_over, bool sup_ove
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
     free_b += c->slot_bytes_lines() + cached_bytes_on(c->device);
+    if (const int mb = env_int("ARCTE_HIP_TEST_GROW_FREE_MB", 0); mb > 0) free_b = std::min<size_t>(free_b, (size_t)mb << 20);      // test hook: a full device
     // (fewer slots by half a wavefront per CU at a time, as setup_lines does; round 4's first version halved them and a whole launch
     //  of the 8M-node graph went from 4 096 slots to 2 048 for 2 % of memory: tools/whole_launch_probe.py)
     int64_t slots = c->l_slots;

@@ -253,6 +253,52 @@ def test_indirect_region_b_pool_grows(monkeypatch):
     assert np.array_equal(sorted_rows(colptr, rows), o_rows)
 
 
+def test_growing_slot_memory_gives_up_slots_half_a_wavefront_per_cu_at_a_time(monkeypatch):
+    """Round 4: when the grown slot memory does not fit, the context keeps as many slots as do -- fewer by half a wavefront per
+    CU at a time, not half of them (the first whole launch of the 8M-node graph lost 2 048 of 4 096 slots that way) -- the
+    wavefronts per CU (and with them the LDS share and the kernel build) follow, and the results stay the oracle's."""
+    from reveal_graph_embedding_amd import _native
+    g = load_golden("rmat2000")
+    w = g["w"]
+    o_colptr, o_rows, _, o_nop, _ = oracle.worker(w, g["out_degree"], g["in_degree"], g["all_seeds"], g["rho"], g["epsilon"], want_stats=True)
+    monkeypatch.setenv("ARCTE_HIP_B_INDIRECT", "1")
+    monkeypatch.setenv("ARCTE_HIP_B_POOL", "64")
+    monkeypatch.setenv("ARCTE_HIP_HOT", "0")
+    monkeypatch.setenv("ARCTE_HIP_LINES_LDS", "64")
+    # what the slots take once every pool has grown to what the graph's heaviest seed claims, with room for all of them
+    with _native.Context(w.indptr, w.indices, w.data, g["out_degree"], g["in_degree"]) as ctx:
+        ctx.run_seeds(g["all_seeds"], g["rho"], g["epsilon"])
+        assert ctx.stats()["reruns"] > 0
+        all_slots = ctx.info()["slots"]
+        grown_bytes = ctx.state_info()["slot_bytes"]
+    # ... and on a device (as the hook shows it) that has 80 % of that: three quarters of it may go to slots
+    room_mb = max(1, int(grown_bytes * 0.8) >> 20)
+    monkeypatch.setenv("ARCTE_HIP_TEST_GROW_FREE_MB", str(room_mb))
+    with _native.Context(w.indptr, w.indices, w.data, g["out_degree"], g["in_degree"]) as ctx:
+        before = ctx.info()
+        cus = before["compute_units"]
+        assert before["slots"] == all_slots
+        ctx.run_seeds(g["all_seeds"], g["rho"], g["epsilon"])
+        assert ctx.stats()["reruns"] > 0
+        after = ctx.info()
+        slot_bytes = ctx.state_info()["slot_bytes"]
+        budget = (room_mb << 20) // 4 * 3
+        assert slot_bytes <= budget
+        assert all_slots // 2 < after["slots"] < all_slots, (all_slots, after["slots"])
+        assert (all_slots - after["slots"]) % max(1, cus // 2) == 0
+        # one more step of half a wavefront per CU would not have fitted
+        assert (after["slots"] + cus // 2) * (slot_bytes // after["slots"]) > budget
+        assert after["waves_per_cu"] == -(-after["slots"] // cus)
+        colptr, rows, nop = ctx.fetch(want_nop=True)
+        assert np.array_equal(colptr, o_colptr) and np.array_equal(nop, o_nop)
+        assert np.array_equal(sorted_rows(colptr, rows), o_rows)
+        # ... and a second run on the smaller context
+        ctx.run_seeds(g["all_seeds"], g["rho"], g["epsilon"])
+        assert ctx.stats()["reruns"] == 0
+        colptr, rows, nop = ctx.fetch(want_nop=True)
+        assert np.array_equal(colptr, o_colptr) and np.array_equal(sorted_rows(colptr, rows), o_rows)
+
+
 @pytest.mark.parametrize("name", ["rmat2000", "ws1000"])
 def test_indirect_region_b_centrality(name, monkeypatch):
     """arcte_and_centrality's seed loop through indirect lines: the reference's own vector, bit for bit."""
